@@ -1,0 +1,212 @@
+/*
+ * scrubvae_hip.h -- C ABI of libscrubvae_hip.so (gfx950 / MI355X).
+ *
+ * The reference (tdunnlab/scrubvae) is pure Python and has NO FFI/plugin boundary
+ * (SURVEY.md 8b); this ABI is new and sits underneath the reference's Python API.  Each
+ * entry point states which reference op (file:line under /root/reference) it replaces.
+ * The Python binding is scrubvae_amd/_lib.py (ctypes); INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every pointer is a DEVICE pointer unless noted;
+ *  - the caller owns every buffer (inputs, outputs, workspaces); the callee never
+ *    allocates, frees, synchronises or keeps a pointer past return;
+ *  - all launches go to the hipStream_t passed as `void* stream`;
+ *  - return value: 0 = ok, negative = svae_status error; svae_last_error() gives text;
+ *  - activations are channels-last ("NLC"): row r = b*L + l, `ld` floats per row, the
+ *    first C entries valid, entries C..Cp-1 (Cp = channels padded to a multiple of 16)
+ *    are zero.  This makes the reference's [B,W,C] <-> [B,C,W] moveaxis copies
+ *    (residual.py:450,479) free;
+ *  - conv / linear weights are "TIO": w[tap][c_in_pad][c_out_pad], pads zero.
+ *    Conv1d weight [Cout,Cin,k]      -> w[t][ci][co] = W[co][ci][t]
+ *    ConvTranspose1d weight [Cin,Cout,k] -> w[t][ci][co] = W[ci][co][t]
+ *    Linear weight [out,in]          -> w[0][in][out].
+ */
+#ifndef SCRUBVAE_HIP_H
+#define SCRUBVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  SVAE_OK = 0,
+  SVAE_ERR_SHAPE = -1,     /* inconsistent / unsupported shape */
+  SVAE_ERR_ALIGN = -2,     /* pointer or leading dimension not 16-byte aligned */
+  SVAE_ERR_WORKSPACE = -3, /* workspace too small */
+  SVAE_ERR_LAUNCH = -4,    /* hipLaunch failed (see svae_last_error) */
+  SVAE_ERR_ARG = -5        /* null pointer / bad enum */
+} svae_status;
+
+#define SVAE_MAX_TAPS 32
+#define SVAE_MAX_JOINTS 32
+#define SVAE_MAX_CHAINS 8
+#define SVAE_MAX_CHAIN_LEN 8
+
+int svae_version(void);
+/* copies the calling thread's last error text into buf (NUL-terminated) */
+void svae_last_error(char* buf, size_t n);
+
+/* ------------------------------------------------------------------ conv / linear --- */
+typedef struct {
+  int batch;
+  int l_in, l_out;   /* sequence lengths; l_out must match the PyTorch formula */
+  int c_in, c_out;   /* padded channel counts, multiples of 16 */
+  int ld_in, ld_out; /* floats per activation row (>= c_in / c_out, multiple of 4) */
+  int kernel, stride, padding, dilation;
+  int transposed;    /* 0 = nn.Conv1d, 1 = nn.ConvTranspose1d; Linear: kernel=1,l=1 */
+} svae_conv_desc;
+
+/* y[b,lo,:] (+)= bias + sum_t x[b,li(lo,t),:] @ w[t]     (residual.py:79-109,137-170,
+ * 198,219-222,264,286: every nn.Conv1d / nn.ConvTranspose1d / nn.Linear of the trunk).
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM, 128xBN tiles. */
+int svae_conv_fwd(const svae_conv_desc* d, const float* x, const float* w, const float* bias,
+                  float* y, int accumulate, void* stream);
+/* dx (+)= conv_backward_input(dy, w)      (autograd of the above) */
+int svae_conv_dgrad(const svae_conv_desc* d, const float* dy, const float* w, float* dx,
+                    int accumulate, void* stream);
+/* dw (+)= conv_backward_weight(x, dy); split-K partial slabs in `ws`, reduced in a fixed
+ * order (bit-reproducible).  db (optional, may be NULL) (+)= column sums of dy. */
+size_t svae_conv_wgrad_workspace(const svae_conv_desc* d);
+int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const float* dy, float* dw,
+                    float* db, void* ws, size_t ws_bytes, int accumulate, void* stream);
+
+/* ------------------------------------------------------------- elementwise / norm --- */
+/* E0: ResVAE.normalize_root + input pack (residual.py:428-431,438-451).
+ * x6d [rows, 6J], root [rows,3], arena = HOST pointer to 6 floats [2,3] (may be NULL:
+ * no root channels)
+ * -> x_in [rows, ld] = [x6d | 2(root-a0)/(a1-a0)-1 | 0 pad]. */
+int svae_pack_input(const float* x6d, const float* root, const float* arena, float* x_in,
+                    long long rows, int n_joints, int ld, void* stream);
+
+/* Train-mode BatchNorm1d statistics (residual.py:88,112,146,173): per-channel partial
+ * sums over row chunks.  part [n_chunks][2][C] (sum, sum of squares); n_chunks returned by
+ * svae_bn_chunks(rows). */
+int svae_bn_chunks(long long rows);
+int svae_bn_stats_partial(const float* x, long long rows, int C, int ld, float* part, void* stream);
+/* Finalize: sums over chunks in fixed order (fp64), `count` = rows over ALL ranks (the
+ * caller all-reduces `part` reduced to [2][C] for sync-BN, see svae_bn_reduce_partials).
+ * Writes scale = gamma*rstd, shift = beta-mean*scale, saves mean/rstd, updates running
+ * stats with momentum (unbiased var) when running_mean != NULL. */
+int svae_bn_reduce_partials(const float* part, int n_chunks, int C, float* sums /*[2][C]*/, void* stream);
+int svae_bn_finalize(const float* sums, double count, int C, const float* gamma, const float* beta,
+                     float eps, float momentum, float* running_mean, float* running_var,
+                     float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* eval mode: scale/shift from running stats */
+int svae_bn_eval_coeffs(int C, const float* gamma, const float* beta, float eps,
+                        const float* running_mean, const float* running_var,
+                        float* scale, float* shift, void* stream);
+/* y = PReLU(x*scale+shift) with scalar slope *alpha (nn.PReLU(), residual.py:89,113,147,
+ * 174,199).  scale/shift NULL => identity affine (conv_in's bare PReLU). */
+int svae_affine_prelu_fwd(const float* x, const float* scale, const float* shift, const float* alpha,
+                          float* y, long long rows, int C, int ld, void* stream);
+/* backward, pass 1: partial column sums  part[n_chunks][2][C] = (sum du, sum du*xhat),
+ * dalpha_part[n_chunks] = sum dy*u*[u<=0]; du = dy*(u>0?1:alpha), u = x*scale+shift. */
+int svae_affine_prelu_bwd_partial(const float* dy, const float* x, const float* scale, const float* shift,
+                                  const float* mean, const float* rstd, const float* alpha,
+                                  long long rows, int C, int ld, float* part, float* dalpha_part,
+                                  void* stream);
+/* pass 2: dx = gamma*rstd*(du - s0/count - xhat*s1/count)  (train-mode BN backward);
+ * with sums == NULL: dx = du*scale (eval BN / bare PReLU: scale may be NULL => 1).
+ * Also (+)= dgamma, dbeta from sums and dalpha from dalpha_part when those pointers are
+ * given (done by block 0 only). */
+int svae_affine_prelu_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift,
+                                const float* mean, const float* rstd, const float* gamma,
+                                const float* alpha, const float* sums, double count,
+                                float* dx, long long rows, int C, int ld,
+                                float* dgamma, float* dbeta, float* dalpha,
+                                const float* dalpha_part, int n_chunks, int accumulate_param_grads,
+                                void* stream);
+
+/* nn.Upsample(scale_factor=2, mode="linear", align_corners=False) (residual.py:160) */
+int svae_upsample2_fwd(const float* x, float* y, int batch, int l_in, int C, int ld, void* stream);
+int svae_upsample2_bwd(const float* dy, float* dx, int batch, int l_in, int C, int ld, int accumulate,
+                       void* stream);
+
+/* ------------------------------------------------------------------- latent heads --- */
+/* E4+S1+L3 (diag): h [B, ld] = [mu | raw]; sigma = softplus(raw) (residual.py:60-68),
+ * z = mu + sigma*eps (residual.py:305-316; eps NULL => z = mu, eval mode),
+ * kl_part[blocks] = per-block partial of -0.5*sum(1+2log(sigma)-mu^2-sigma^2)
+ * (losses.py:138-146, before the /B). */
+int svae_heads_diag_fwd(const float* h, int ld, const float* eps, float* mu, float* sigma, float* z,
+                        int ldz, float* kl_part, int batch, int zdim, void* stream);
+int svae_heads_blocks(int batch, int zdim);
+/* dh = [dmu_total | draw]: dmu_total = dmu + dz + kl_scale*mu,
+ * draw = (dz*eps + dsigma + kl_scale*(sigma-1/sigma)) * sigmoid(raw). */
+int svae_heads_diag_bwd(const float* h, int ld, const float* eps, const float* sigma,
+                        const float* dz, int lddz, const float* dmu, const float* dsigma, float kl_scale,
+                        float* dh, int batch, int zdim, void* stream);
+
+/* ----------------------------------------------------------------- pose-loss tail --- */
+typedef struct {
+  int n_joints;
+  int n_chains;
+  int chain_len[SVAE_MAX_CHAINS];
+  int chain[SVAE_MAX_CHAINS][SVAE_MAX_CHAIN_LEN];
+} svae_tree;
+
+/* D3 tail + K1 + K3 + L1 + L2 fused, one pass over the decoder output:
+ *   y [rows, ld] conv_out pre-activation -> x_hat = tanh(y)            (residual.py:291)
+ *   x6d_hat [rows, 6J], root_hat [rows,3] = inv_normalize_root(...)     (residual.py:479-489)
+ *   pose_hat = fwd_kin_cont6d_torch(x6d_hat, tree, offsets, root=0, eps=1e-8)
+ *                                                     (dataset.py:83-116, quaternion.py:337-353)
+ *   jpe partial  = sum (target_pose - pose_hat)^2     (losses.py:148-171, before /(B*3*J))
+ *   root partial = sum (root_hat - root)^2            (losses.py:216-219, before /B)
+ *   dy [rows, ld] = jpe_scale * d jpe_sum/dy + root_scale * d root_sum/dy   (analytic
+ *   reverse-mode through the kinematic chains, the 6D->matrix map and tanh).
+ * `arena` is a HOST pointer to 6 floats (NULL: no root channels).
+ * loss_part [blocks][2].  dy may be NULL (eval: forward only).  ext_dx6d/ext_droot
+ * (optional) are extra upstream grads w.r.t. x6d_hat/root_hat added before the tanh
+ * backward (used by the rotation loss and by autograd callers). */
+int svae_tail_blocks(long long rows);
+int svae_pose_tail(const float* y, int ld, const float* offsets, const float* target_pose,
+                   const float* root, const float* arena, const svae_tree* tree,
+                   float jpe_scale, float root_scale, const float* ext_dx6d, const float* ext_droot,
+                   float* x6d_hat, float* root_hat, float* loss_part, float* dy,
+                   long long rows, void* stream);
+
+/* L4: stable_rotation_loss (losses.py:123-136, rotation_conversion.py:469-488):
+ * part[blocks] partial sums of 2*asin(clamp(|R(x_hat)-R(x)|_F/2^1.5)); dx6d_hat (optional)
+ * = scale * d/dx_hat. n = rows*J six-vectors. */
+int svae_rot_loss(const float* x6d, const float* x6d_hat, float scale, float* part, float* dx6d_hat,
+                  long long n, void* stream);
+int svae_rot_blocks(long long n);
+
+/* ------------------------------------------------------------------------- optimizer --- */
+/* O1: torch.optim.AdamW / Adam step over one flat fp32 buffer (trainer.py:60-65,165).
+ * step_t = 1-based step count; decoupled != 0 => AdamW. grad_scale multiplies g first
+ * (1/world_size after a sum all-reduce, or the clip coefficient). */
+int svae_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step_t, int decoupled,
+                   float grad_scale, void* stream);
+/* sum of squares partials for clip_grad_norm_ (trainer.py:164): part[svae_sumsq_blocks(n)] */
+int svae_sumsq_blocks(long long n);
+int svae_sumsq_partial(const float* x, long long n, float* part, void* stream);
+/* out[0..k) = sum over rows of part[rows][k] in fixed order (fp64 accumulate) * scale */
+int svae_reduce_rows(const float* part, int rows, int k, float scale, float* out, int accumulate, void* stream);
+
+/* ----------------------------------------------------------- small elementwise ops --- */
+int svae_relu_fwd(const float* x, float* y, long long n, void* stream);
+int svae_relu_bwd(const float* dy, const float* y, float* dx, long long n, void* stream);
+int svae_axpy(float a, const float* x, float* y, long long n, void* stream); /* y += a*x */
+int svae_fill(float* x, float v, long long n, void* stream);
+/* G3: sum of squared error vs target, rows x C (pred ld, target ld_t); part[blocks];
+ * dpred (optional) = scale*2*(pred-target) */
+int svae_mse_sum(const float* pred, int ld, const float* target, int ld_t, int rows, int C, float scale,
+                 float* part, float* dpred, void* stream);
+int svae_rowloss_blocks(int rows);
+/* CrossEntropyLoss(reduction="sum") on logits with integer labels (losses.py:271-273) */
+int svae_ce_sum(const float* logits, int ld, const int* labels, int rows, int C, float scale,
+                float* part, float* dlogits, void* stream);
+/* A1: softmax then CrossEntropyLoss(sum) on the softmax OUTPUT against one-hot class
+ * `cls(row) = row >= rows/2` (double softmax, disentangle.py:675 + losses.py:297-307) */
+int svae_double_softmax_ce_sum(const float* logits, int ld, int rows, float scale, float* part,
+                               float* dlogits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

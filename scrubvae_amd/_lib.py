@@ -1,0 +1,115 @@
+"""ctypes binding of libscrubvae_hip.so (include/scrubvae_hip.h).
+
+The product path has NO fallback: if the HIP library is missing this module raises at
+import of the first op, and every op raises RuntimeError on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libscrubvae_hip.so")
+
+MAX_TAPS, MAX_JOINTS, MAX_CHAINS, MAX_CHAIN_LEN = 32, 32, 8, 8
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "batch", "l_in", "l_out", "c_in", "c_out", "ld_in", "ld_out",
+        "kernel", "stride", "padding", "dilation", "transposed")]
+
+
+class Tree(C.Structure):
+    _fields_ = [("n_joints", C.c_int), ("n_chains", C.c_int),
+                ("chain_len", C.c_int * MAX_CHAINS),
+                ("chain", (C.c_int * MAX_CHAIN_LEN) * MAX_CHAINS)]
+
+
+def make_tree(n_joints, kinematic_tree):
+    t = Tree()
+    t.n_joints = n_joints
+    if len(kinematic_tree) > MAX_CHAINS:
+        raise ValueError(f"kinematic tree has {len(kinematic_tree)} chains > {MAX_CHAINS}")
+    t.n_chains = len(kinematic_tree)
+    for c, chain in enumerate(kinematic_tree):
+        if len(chain) > MAX_CHAIN_LEN:
+            raise ValueError(f"chain {c} longer than {MAX_CHAIN_LEN}")
+        t.chain_len[c] = len(chain)
+        for i, j in enumerate(chain):
+            t.chain[c][i] = int(j)
+    return t
+
+
+P, I, LL, F, D, SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_size_t
+DP = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol include/scrubvae_hip.h declares
+SIGNATURES = {
+    "svae_version": (I, []),
+    "svae_last_error": (None, [C.c_char_p, SZ]),
+    "svae_conv_fwd": (I, [DP, P, P, P, P, I, P]),
+    "svae_conv_dgrad": (I, [DP, P, P, P, I, P]),
+    "svae_conv_wgrad_workspace": (SZ, [DP]),
+    "svae_conv_wgrad": (I, [DP, P, P, P, P, P, SZ, I, P]),
+    "svae_pack_input": (I, [P, P, C.POINTER(F), P, LL, I, I, P]),
+    "svae_bn_chunks": (I, [LL]),
+    "svae_bn_stats_partial": (I, [P, LL, I, I, P, P]),
+    "svae_bn_reduce_partials": (I, [P, I, I, P, P]),
+    "svae_bn_finalize": (I, [P, D, I, P, P, F, F, P, P, P, P, P, P, P]),
+    "svae_bn_eval_coeffs": (I, [I, P, P, F, P, P, P, P, P]),
+    "svae_affine_prelu_fwd": (I, [P, P, P, P, P, LL, I, I, P]),
+    "svae_affine_prelu_bwd_partial": (I, [P, P, P, P, P, P, P, LL, I, I, P, P, P]),
+    "svae_affine_prelu_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, D, P, LL, I, I, P, P, P, P, I, I, P]),
+    "svae_upsample2_fwd": (I, [P, P, I, I, I, I, P]),
+    "svae_upsample2_bwd": (I, [P, P, I, I, I, I, I, P]),
+    "svae_heads_diag_fwd": (I, [P, I, P, P, P, P, I, P, I, I, P]),
+    "svae_heads_blocks": (I, [I, I]),
+    "svae_heads_diag_bwd": (I, [P, I, P, P, P, I, P, P, F, P, I, I, P]),
+    "svae_tail_blocks": (I, [LL]),
+    "svae_pose_tail": (I, [P, I, P, P, P, C.POINTER(F), C.POINTER(Tree), F, F, P, P, P, P, P, P, LL, P]),
+    "svae_rot_loss": (I, [P, P, F, P, P, LL, P]),
+    "svae_rot_blocks": (I, [LL]),
+    "svae_adam_step": (I, [P, P, P, P, LL, F, F, F, F, F, I, I, F, P]),
+    "svae_sumsq_blocks": (I, [LL]),
+    "svae_sumsq_partial": (I, [P, LL, P, P]),
+    "svae_reduce_rows": (I, [P, I, I, F, P, I, P]),
+    "svae_relu_fwd": (I, [P, P, LL, P]),
+    "svae_relu_bwd": (I, [P, P, P, LL, P]),
+    "svae_axpy": (I, [F, P, P, LL, P]),
+    "svae_fill": (I, [P, F, LL, P]),
+    "svae_mse_sum": (I, [P, I, P, I, I, I, F, P, P, P]),
+    "svae_rowloss_blocks": (I, [I]),
+    "svae_ce_sum": (I, [P, I, P, I, I, F, P, P, P]),
+    "svae_double_softmax_ce_sum": (I, [P, I, I, F, P, P, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it was not built: there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  scrubvae_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    lib().svae_last_error(buf, 512)
+    return buf.value.decode()
+
+
+def check(status, what=""):
+    if status != 0:
+        raise RuntimeError(f"libscrubvae_hip {what} failed (status {status}): {last_error()}")

@@ -1,0 +1,630 @@
+// HBM-bound row/channel kernels of the SC-VAE step (gfx950): input pack, train-mode
+// BatchNorm statistics, fused BN-affine + PReLU forward/backward, linear x2 upsample,
+// latent heads (softplus / reparameterisation / KL), small loss reductions, fused Adam.
+// All activations are channels-last [rows][ld] fp32; every kernel moves 16 bytes per lane.
+#include "svae_internal.h"
+
+namespace svae {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+static inline int grid_for(long long work_items, int per_block = 256, int cap = 4096) {
+  long long b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------ pack input
+struct Arena { float a0[3], a1[3]; int valid; };
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x6d, const float* __restrict__ root,
+                                                          const Arena arena, float* __restrict__ out,
+                                                          long long rows, int c6, int ld) {
+  const long long total = rows * ld;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / ld;
+    const int c = (int)(i - r * ld);
+    float v = 0.f;
+    if (c < c6) {
+      v = x6d[r * c6 + c];
+    } else if (arena.valid && c < c6 + 3) {
+      const int a = c - c6;
+      const float a0 = arena.a0[a], a1 = arena.a1[a];
+      v = 2.f * (root[r * 3 + a] - a0) / (a1 - a0) - 1.f;
+    }
+    out[i] = v;
+  }
+}
+
+// --------------------------------------------------------------------------- BN stats
+constexpr int STAT_ROWS = 512;
+
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long long rows, int C, int ld,
+                                                                float* __restrict__ part) {
+  __shared__ float red[2][16][65];
+  const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.y * 64 + c4 * 4;
+  const long long r0 = (long long)blockIdx.x * STAT_ROWS;
+  long long r1 = r0 + STAT_ROWS;
+  if (r1 > rows) r1 = rows;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+  if (c < C)
+    for (long long r = r0 + rl; r < r1; r += 16) {
+      const float4 v = ld4(x + r * ld + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+    }
+  red[0][rl][c4 * 4 + 0] = s.x; red[0][rl][c4 * 4 + 1] = s.y; red[0][rl][c4 * 4 + 2] = s.z; red[0][rl][c4 * 4 + 3] = s.w;
+  red[1][rl][c4 * 4 + 0] = q.x; red[1][rl][c4 * 4 + 1] = q.y; red[1][rl][c4 * 4 + 2] = q.z; red[1][rl][c4 * 4 + 3] = q.w;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int k = threadIdx.x >> 6, cc = threadIdx.x & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[k][i][cc];
+    const int col = blockIdx.y * 64 + cc;
+    if (col < C) part[((long long)blockIdx.x * 2 + k) * C + col] = t;
+  }
+}
+
+// sums[k][c] = sum over chunks (fp64, fixed order)
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int chunks, int K, int C, float* __restrict__ sums) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * C) return;
+  const int k = i / C, c = i - k * C;
+  double s = 0.0;
+  for (int ch = 0; ch < chunks; ++ch) s += (double)part[((long long)ch * K + k) * C + c];
+  sums[i] = (float)s;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, double count, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* mean_o, float* rstd_o, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = (double)sums[c] / count;
+  double var = (double)sums[C + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma[c], b = beta[c];
+  mean_o[c] = (float)mean;
+  rstd_o[c] = rstd;
+  scale[c] = g * rstd;
+  shift[c] = b - (float)mean * g * rstd;
+  if (running_mean != nullptr) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.f / sqrtf(rv[c] + eps);
+  scale[c] = gamma[c] * rstd;
+  shift[c] = beta[c] - rm[c] * gamma[c] * rstd;
+}
+
+// ------------------------------------------------------------- affine + PReLU forward
+__global__ __launch_bounds__(256) void affine_prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ alpha,
+                                                                float* __restrict__ y, long long rows, int C4, int ld) {
+  const float a = alpha[0];
+  const long long total = rows * C4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    float4 v = ld4(x + r * ld + c);
+    if (scale != nullptr) {
+      const float4 s = ld4(scale + c), t = ld4(shift + c);
+      v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
+    }
+    v.x = v.x > 0.f ? v.x : a * v.x; v.y = v.y > 0.f ? v.y : a * v.y;
+    v.z = v.z > 0.f ? v.z : a * v.z; v.w = v.w > 0.f ? v.w : a * v.w;
+    st4(y + r * ld + c, v);
+  }
+}
+
+// backward pass 1: part[chunk][2][C] = (sum du, sum du*xhat); dalpha_part[chunk*gridDim.y + by]
+__global__ __launch_bounds__(256) void affine_prelu_bwd_partial_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ alpha, long long rows, int C, int ld,
+    float* __restrict__ part, float* __restrict__ dalpha_part) {
+  __shared__ float red[2][16][65];
+  __shared__ float red4[4];
+  const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.y * 64 + c4 * 4;
+  const long long r0 = (long long)blockIdx.x * STAT_ROWS;
+  long long r1 = r0 + STAT_ROWS;
+  if (r1 > rows) r1 = rows;
+  const float a = alpha[0];
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  float da = 0.f;
+  if (c < C) {
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (scale != nullptr) {
+      const float4 t0 = ld4(scale + c), t1 = ld4(shift + c);
+      sc[0] = t0.x; sc[1] = t0.y; sc[2] = t0.z; sc[3] = t0.w;
+      sh[0] = t1.x; sh[1] = t1.y; sh[2] = t1.z; sh[3] = t1.w;
+    }
+    if (mean != nullptr) {
+      const float4 t0 = ld4(mean + c), t1 = ld4(rstd + c);
+      mu[0] = t0.x; mu[1] = t0.y; mu[2] = t0.z; mu[3] = t0.w;
+      rs[0] = t1.x; rs[1] = t1.y; rs[2] = t1.z; rs[3] = t1.w;
+    }
+    for (long long r = r0 + rl; r < r1; r += 16) {
+      const float4 xv4 = ld4(x + r * ld + c), dv4 = ld4(dy + r * ld + c);
+      const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float u = xv[k] * sc[k] + sh[k];
+        const float du = u > 0.f ? dv[k] : a * dv[k];
+        if (!(u > 0.f)) da += dv[k] * u;
+        s0[k] += du;
+        s1[k] += du * (xv[k] - mu[k]) * rs[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[0][rl][c4 * 4 + k] = s0[k]; red[1][rl][c4 * 4 + k] = s1[k]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int k = threadIdx.x >> 6, cc = threadIdx.x & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[k][i][cc];
+    const int col = blockIdx.y * 64 + cc;
+    if (col < C) part[((long long)blockIdx.x * 2 + k) * C + col] = t;
+  }
+  const float tot = block_sum_256(da, red4);
+  if (threadIdx.x == 0) dalpha_part[(long long)blockIdx.x * gridDim.y + blockIdx.y] = tot;
+}
+
+// backward pass 2
+__global__ __launch_bounds__(256) void affine_prelu_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+    const float* __restrict__ alpha, const float* __restrict__ sums, float inv_count, float* __restrict__ dx, long long rows,
+    int C, int ld) {
+  const float a = alpha[0];
+  const int C4 = C / 4;
+  const long long total = rows * C4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    const float4 xv4 = ld4(x + r * ld + c), dv4 = ld4(dy + r * ld + c);
+    const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float sc = scale ? scale[c + k] : 1.f, sh = scale ? shift[c + k] : 0.f;
+      const float u = xv[k] * sc + sh;
+      const float du = u > 0.f ? dv[k] : a * dv[k];
+      if (sums != nullptr) {
+        const float xh = (xv[k] - mean[c + k]) * rstd[c + k];
+        o[k] = gamma[c + k] * rstd[c + k] * (du - sums[c + k] * inv_count - xh * sums[C + c + k] * inv_count);
+      } else {
+        o[k] = du * sc;
+      }
+    }
+    st4(dx + r * ld + c, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+__global__ void bn_param_grads_kernel(const float* __restrict__ sums, int C, float* dgamma, float* dbeta, float* dalpha,
+                                      const float* __restrict__ dalpha_part, int n_parts, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sums != nullptr && c < C) {
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + sums[c];
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + sums[C + c];
+  }
+  if (c == 0 && dalpha != nullptr) {
+    double s = 0.0;
+    for (int i = 0; i < n_parts; ++i) s += (double)dalpha_part[i];
+    dalpha[0] = (accumulate ? dalpha[0] : 0.f) + (float)s;
+  }
+}
+
+// ------------------------------------------------------------------------- upsample x2
+__global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int batch, int L,
+                                                             int C4, int ld) {
+  const long long total = (long long)batch * 2 * L * C4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long row = i / C4;
+    const int c = (int)(i - row * C4) * 4;
+    const long long b = row / (2 * L);
+    const int ro = (int)(row - b * 2 * L);
+    const int ii = ro >> 1;
+    const int i2 = (ro & 1) ? (ii + 1 < L ? ii + 1 : L - 1) : (ii > 0 ? ii - 1 : 0);
+    const float4 p = ld4(x + (b * L + ii) * ld + c), q = ld4(x + (b * L + i2) * ld + c);
+    st4(y + row * ld + c, make_float4(0.75f * p.x + 0.25f * q.x, 0.75f * p.y + 0.25f * q.y, 0.75f * p.z + 0.25f * q.z,
+                                      0.75f * p.w + 0.25f * q.w));
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int batch, int L,
+                                                             int C4, int ld, int accumulate) {
+  const long long total = (long long)batch * L * C4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long row = i / C4;
+    const int c = (int)(i - row * C4) * 4;
+    const long long b = row / L;
+    const int ii = (int)(row - b * L);
+    const float* base = dy + b * 2 * L * ld + c;
+    const float4 e = ld4(base + (long long)(2 * ii) * ld), o = ld4(base + (long long)(2 * ii + 1) * ld);
+    const float4 nx = ld4(base + (long long)(ii + 1 < L ? 2 * ii + 2 : 2 * L - 1) * ld);
+    const float4 pv = ld4(base + (long long)(ii >= 1 ? 2 * ii - 1 : 0) * ld);
+    float4 r = make_float4(0.75f * (e.x + o.x) + 0.25f * (nx.x + pv.x), 0.75f * (e.y + o.y) + 0.25f * (nx.y + pv.y),
+                           0.75f * (e.z + o.z) + 0.25f * (nx.z + pv.z), 0.75f * (e.w + o.w) + 0.25f * (nx.w + pv.w));
+    if (accumulate) {
+      const float4 old = ld4(dx + row * ld + c);
+      r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w;
+    }
+    st4(dx + row * ld + c, r);
+  }
+}
+
+// ------------------------------------------------------------------------ latent heads
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__global__ __launch_bounds__(256) void heads_diag_fwd_kernel(const float* __restrict__ h, int ld, const float* __restrict__ eps,
+                                                              float* __restrict__ mu, float* __restrict__ sigma,
+                                                              float* __restrict__ z, int ldz, float* __restrict__ kl_part, int batch,
+                                                              int zd) {
+  __shared__ float red4[4];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  float kl = 0.f;
+  if (i < (long long)batch * zd) {
+    const int b = (int)(i / zd), k = (int)(i - (long long)b * zd);
+    const float m = h[(long long)b * ld + k];
+    const float s = softplus_f(h[(long long)b * ld + zd + k]);
+    mu[i] = m;
+    sigma[i] = s;
+    z[(long long)b * ldz + k] = eps ? m + s * eps[i] : m;
+    kl = -0.5f * (1.f + 2.f * logf(s) - m * m - s * s);
+  }
+  const float t = block_sum_256(kl, red4);
+  if (threadIdx.x == 0) kl_part[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void heads_diag_bwd_kernel(const float* __restrict__ h, int ld, const float* __restrict__ eps,
+                                                              const float* __restrict__ sigma, const float* __restrict__ dz, int lddz,
+                                                              const float* __restrict__ dmu, const float* __restrict__ dsigma,
+                                                              float kl_scale, float* __restrict__ dh, int batch, int zd) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)batch * zd) return;
+  const int b = (int)(i / zd), k = (int)(i - (long long)b * zd);
+  const float m = h[(long long)b * ld + k], raw = h[(long long)b * ld + zd + k];
+  const float s = sigma[i];
+  const float gz = dz ? dz[(long long)b * lddz + k] : 0.f;
+  float gm = gz + kl_scale * m;
+  if (dmu) gm += dmu[i];
+  float gs = kl_scale * (s - 1.f / s);
+  if (eps) gs += gz * eps[i];
+  if (dsigma) gs += dsigma[i];
+  const float sig = 1.f / (1.f + expf(-raw));
+  dh[(long long)b * ld + k] = gm;
+  dh[(long long)b * ld + zd + k] = gs * sig;
+}
+
+// -------------------------------------------------------------------------- optimizer
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                    float wd, float step_size, float inv_bc2_sqrt, int decoupled, float gscale) {
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 pv = ld4(p + i * 4), gv = ld4(g + i * 4), mv = ld4(m + i * 4), vv = ld4(v + i * 4);
+    float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w},
+          vq[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gk = gg[k] * gscale;
+      if (decoupled) pp[k] *= (1.f - lr * wd);
+      else if (wd != 0.f) gk += wd * pp[k];
+      mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+      vq[k] = b2 * vq[k] + (1.f - b2) * gk * gk;
+      const float denom = sqrtf(vq[k]) * inv_bc2_sqrt + eps;
+      pp[k] -= step_size * mm[k] / denom;
+    }
+    st4(p + i * 4, make_float4(pp[0], pp[1], pp[2], pp[3]));
+    st4(m + i * 4, make_float4(mm[0], mm[1], mm[2], mm[3]));
+    st4(v + i * 4, make_float4(vq[0], vq[1], vq[2], vq[3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
+  __shared__ float red4[4];
+  float s = 0.f;
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = ld4(x + i * 4);
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  const float t = block_sum_256(s, red4);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+__global__ void reduce_rows_kernel(const float* __restrict__ part, int rows, int k, float scale, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)part[(long long)r * k + c];
+  out[c] = (accumulate ? out[c] : 0.f) + (float)(s * (double)scale);
+}
+
+// ------------------------------------------------------------------ small elementwise
+__global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = x[i] > 0.f ? x[i] : 0.f;
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+__global__ void axpy_kernel(float a, const float* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] += a * x[i];
+}
+__global__ void fill_kernel(float* __restrict__ x, float v, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] = v;
+}
+
+// row-wise losses: one thread per row, 256 rows per block
+__global__ __launch_bounds__(256) void mse_sum_kernel(const float* __restrict__ pred, int ld, const float* __restrict__ target,
+                                                       int ld_t, int rows, int C, float scale, float* __restrict__ part,
+                                                       float* __restrict__ dpred) {
+  __shared__ float red4[4];
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  float s = 0.f;
+  if (r < rows)
+    for (int c = 0; c < C; ++c) {
+      const float d = pred[(long long)r * ld + c] - target[(long long)r * ld_t + c];
+      s += d * d;
+      if (dpred) dpred[(long long)r * ld + c] = 2.f * scale * d;
+    }
+  const float t = block_sum_256(s, red4);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void ce_sum_kernel(const float* __restrict__ logits, int ld, const int* __restrict__ labels,
+                                                      int rows, int C, float scale, float* __restrict__ part,
+                                                      float* __restrict__ dlogits) {
+  __shared__ float red4[4];
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  float loss = 0.f;
+  if (r < rows) {
+    const float* x = logits + (long long)r * ld;
+    float mx = x[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+    const float lse = mx + logf(se);
+    const int y = labels[r];
+    loss = lse - x[y];
+    if (dlogits)
+      for (int c = 0; c < C; ++c) dlogits[(long long)r * ld + c] = scale * (expf(x[c] - lse) - (c == y ? 1.f : 0.f));
+  }
+  const float t = block_sum_256(loss, red4);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// two classes: p = softmax(x); loss = -log_softmax(p)[cls]; cls = row >= rows/2
+__global__ __launch_bounds__(256) void double_softmax_ce_kernel(const float* __restrict__ logits, int ld, int rows, float scale,
+                                                                 float* __restrict__ part, float* __restrict__ dlogits) {
+  __shared__ float red4[4];
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  float loss = 0.f;
+  if (r < rows) {
+    const float x0 = logits[(long long)r * ld], x1 = logits[(long long)r * ld + 1];
+    const float mx = fmaxf(x0, x1);
+    const float e0 = expf(x0 - mx), e1 = expf(x1 - mx);
+    const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+    const float m2 = fmaxf(p0, p1);
+    const float lse = m2 + logf(expf(p0 - m2) + expf(p1 - m2));
+    const int cls = r >= rows / 2 ? 1 : 0;
+    loss = lse - (cls ? p1 : p0);
+    if (dlogits) {
+      // dL/dp_c = softmax(p)_c - [c==cls]; then through p = softmax(x)
+      const float q0 = expf(p0 - lse), q1 = expf(p1 - lse);
+      const float g0 = q0 - (cls == 0 ? 1.f : 0.f), g1 = q1 - (cls == 1 ? 1.f : 0.f);
+      const float dot = g0 * p0 + g1 * p1;
+      dlogits[(long long)r * ld] = scale * p0 * (g0 - dot);
+      dlogits[(long long)r * ld + 1] = scale * p1 * (g1 - dot);
+    }
+  }
+  const float t = block_sum_256(loss, red4);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+}  // namespace svae
+
+using namespace svae;
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int svae_pack_input(const float* x6d, const float* root, const float* arena, float* x_in, long long rows,
+                               int n_joints, int ld, void* stream) {
+  SVAE_REQUIRE(x6d && x_in && rows > 0, SVAE_ERR_ARG, "pack_input: null pointer / no rows");
+  const int c6 = 6 * n_joints;
+  SVAE_REQUIRE(ld >= c6 + (arena ? 3 : 0), SVAE_ERR_SHAPE, "pack_input: ld %d too small", ld);
+  SVAE_REQUIRE(!arena || root, SVAE_ERR_ARG, "pack_input: arena given without root");
+  Arena ar;
+  memset(&ar, 0, sizeof(ar));
+  if (arena) { for (int k = 0; k < 3; ++k) { ar.a0[k] = arena[k]; ar.a1[k] = arena[3 + k]; } ar.valid = 1; }
+  hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(rows * ld)), dim3(256), 0, ST(stream), x6d, root, ar, x_in, rows, c6, ld);
+  return check_launch("pack_input");
+}
+
+extern "C" int svae_bn_chunks(long long rows) { return (int)((rows + STAT_ROWS - 1) / STAT_ROWS); }
+
+extern "C" int svae_bn_stats_partial(const float* x, long long rows, int C, int ld, float* part, void* stream) {
+  SVAE_REQUIRE(x && part && rows > 0, SVAE_ERR_ARG, "bn_stats: null pointer");
+  SVAE_REQUIRE(C % 4 == 0 && ld % 4 == 0 && aligned16(x), SVAE_ERR_ALIGN, "bn_stats: C, ld must be multiples of 4");
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(svae_bn_chunks(rows), (C + 63) / 64), dim3(256), 0, ST(stream), x, rows, C, ld, part);
+  return check_launch("bn_stats_partial");
+}
+
+extern "C" int svae_bn_reduce_partials(const float* part, int n_chunks, int C, float* sums, void* stream) {
+  SVAE_REQUIRE(part && sums && n_chunks > 0, SVAE_ERR_ARG, "bn_reduce_partials: bad args");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, ST(stream), part, n_chunks, 2, C, sums);
+  return check_launch("bn_reduce_partials");
+}
+
+extern "C" int svae_bn_finalize(const float* sums, double count, int C, const float* gamma, const float* beta, float eps,
+                                float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
+                                float* scale, float* shift, void* stream) {
+  SVAE_REQUIRE(sums && gamma && beta && mean && rstd && scale && shift && count > 0, SVAE_ERR_ARG, "bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), sums, count, C, gamma, beta, eps,
+                     momentum, running_mean, running_var, mean, rstd, scale, shift);
+  return check_launch("bn_finalize");
+}
+
+extern "C" int svae_bn_eval_coeffs(int C, const float* gamma, const float* beta, float eps, const float* running_mean,
+                                   const float* running_var, float* scale, float* shift, void* stream) {
+  SVAE_REQUIRE(gamma && beta && running_mean && running_var && scale && shift, SVAE_ERR_ARG, "bn_eval_coeffs: null pointer");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), C, gamma, beta, eps, running_mean,
+                     running_var, scale, shift);
+  return check_launch("bn_eval_coeffs");
+}
+
+extern "C" int svae_affine_prelu_fwd(const float* x, const float* scale, const float* shift, const float* alpha, float* y,
+                                     long long rows, int C, int ld, void* stream) {
+  SVAE_REQUIRE(x && y && alpha && rows > 0, SVAE_ERR_ARG, "affine_prelu_fwd: null pointer");
+  SVAE_REQUIRE(C % 4 == 0 && ld % 4 == 0, SVAE_ERR_ALIGN, "affine_prelu_fwd: C, ld must be multiples of 4");
+  hipLaunchKernelGGL(affine_prelu_fwd_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, ST(stream), x, scale, shift, alpha, y,
+                     rows, C / 4, ld);
+  return check_launch("affine_prelu_fwd");
+}
+
+extern "C" int svae_affine_prelu_bwd_partial(const float* dy, const float* x, const float* scale, const float* shift,
+                                             const float* mean, const float* rstd, const float* alpha, long long rows, int C,
+                                             int ld, float* part, float* dalpha_part, void* stream) {
+  SVAE_REQUIRE(dy && x && alpha && part && dalpha_part && rows > 0, SVAE_ERR_ARG, "affine_prelu_bwd_partial: null pointer");
+  SVAE_REQUIRE(C % 4 == 0 && ld % 4 == 0, SVAE_ERR_ALIGN, "affine_prelu_bwd_partial: C, ld must be multiples of 4");
+  hipLaunchKernelGGL(affine_prelu_bwd_partial_kernel, dim3(svae_bn_chunks(rows), (C + 63) / 64), dim3(256), 0, ST(stream), dy, x,
+                     scale, shift, mean, rstd, alpha, rows, C, ld, part, dalpha_part);
+  return check_launch("affine_prelu_bwd_partial");
+}
+
+extern "C" int svae_affine_prelu_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift,
+                                           const float* mean, const float* rstd, const float* gamma, const float* alpha,
+                                           const float* sums, double count, float* dx, long long rows, int C, int ld,
+                                           float* dgamma, float* dbeta, float* dalpha, const float* dalpha_part, int n_chunks,
+                                           int accumulate_param_grads, void* stream) {
+  SVAE_REQUIRE(dy && x && alpha && dx && rows > 0, SVAE_ERR_ARG, "affine_prelu_bwd_apply: null pointer");
+  SVAE_REQUIRE(!sums || (mean && rstd && gamma && count > 0), SVAE_ERR_ARG, "affine_prelu_bwd_apply: BN tensors missing");
+  hipLaunchKernelGGL(affine_prelu_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, ST(stream), dy, x, scale, shift,
+                     mean, rstd, gamma, alpha, sums, sums ? (float)(1.0 / count) : 0.f, dx, rows, C, ld);
+  if (int e = check_launch("affine_prelu_bwd_apply")) return e;
+  if (dgamma || dbeta || dalpha) {
+    const int n_parts = n_chunks * ((C + 63) / 64);
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), sums, C, dgamma, dbeta, dalpha,
+                       dalpha_part, n_parts, accumulate_param_grads);
+    return check_launch("bn_param_grads");
+  }
+  return SVAE_OK;
+}
+
+extern "C" int svae_upsample2_fwd(const float* x, float* y, int batch, int l_in, int C, int ld, void* stream) {
+  SVAE_REQUIRE(x && y && batch > 0 && l_in > 0 && C % 4 == 0 && ld % 4 == 0, SVAE_ERR_ARG, "upsample2_fwd: bad args");
+  hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(grid_for((long long)batch * 2 * l_in * (C / 4))), dim3(256), 0, ST(stream), x, y,
+                     batch, l_in, C / 4, ld);
+  return check_launch("upsample2_fwd");
+}
+
+extern "C" int svae_upsample2_bwd(const float* dy, float* dx, int batch, int l_in, int C, int ld, int accumulate, void* stream) {
+  SVAE_REQUIRE(dy && dx && batch > 0 && l_in > 0 && C % 4 == 0 && ld % 4 == 0, SVAE_ERR_ARG, "upsample2_bwd: bad args");
+  hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(grid_for((long long)batch * l_in * (C / 4))), dim3(256), 0, ST(stream), dy, dx,
+                     batch, l_in, C / 4, ld, accumulate);
+  return check_launch("upsample2_bwd");
+}
+
+extern "C" int svae_heads_blocks(int batch, int zdim) { return (int)(((long long)batch * zdim + 255) / 256); }
+
+extern "C" int svae_heads_diag_fwd(const float* h, int ld, const float* eps, float* mu, float* sigma, float* z, int ldz,
+                                   float* kl_part, int batch, int zdim, void* stream) {
+  SVAE_REQUIRE(h && mu && sigma && z && kl_part && batch > 0 && zdim > 0 && ld >= 2 * zdim && ldz >= zdim, SVAE_ERR_ARG,
+               "heads_diag_fwd: bad args");
+  hipLaunchKernelGGL(heads_diag_fwd_kernel, dim3(svae_heads_blocks(batch, zdim)), dim3(256), 0, ST(stream), h, ld, eps, mu, sigma,
+                     z, ldz, kl_part, batch, zdim);
+  return check_launch("heads_diag_fwd");
+}
+
+extern "C" int svae_heads_diag_bwd(const float* h, int ld, const float* eps, const float* sigma, const float* dz, int lddz,
+                                   const float* dmu, const float* dsigma, float kl_scale, float* dh, int batch, int zdim,
+                                   void* stream) {
+  SVAE_REQUIRE(h && sigma && dh && batch > 0 && zdim > 0, SVAE_ERR_ARG, "heads_diag_bwd: bad args");
+  hipLaunchKernelGGL(heads_diag_bwd_kernel, dim3(svae_heads_blocks(batch, zdim)), dim3(256), 0, ST(stream), h, ld, eps, sigma, dz,
+                     lddz, dmu, dsigma, kl_scale, dh, batch, zdim);
+  return check_launch("heads_diag_bwd");
+}
+
+extern "C" int svae_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int step_t, int decoupled, float grad_scale, void* stream) {
+  SVAE_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0 && step_t >= 1, SVAE_ERR_ARG, "adam_step: bad args (n must be a multiple of 4)");
+  const double bc1 = 1.0 - pow((double)beta1, step_t), bc2 = 1.0 - pow((double)beta2, step_t);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), decoupled, grad_scale);
+  return check_launch("adam_step");
+}
+
+extern "C" int svae_sumsq_blocks(long long n) { return grid_for(n / 4, 256, 1024); }
+
+extern "C" int svae_sumsq_partial(const float* x, long long n, float* part, void* stream) {
+  SVAE_REQUIRE(x && part && n > 0 && n % 4 == 0, SVAE_ERR_ARG, "sumsq_partial: bad args");
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(svae_sumsq_blocks(n)), dim3(256), 0, ST(stream), x, n, part);
+  return check_launch("sumsq_partial");
+}
+
+extern "C" int svae_reduce_rows(const float* part, int rows, int k, float scale, float* out, int accumulate, void* stream) {
+  SVAE_REQUIRE(part && out && rows > 0 && k > 0, SVAE_ERR_ARG, "reduce_rows: bad args");
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((k + 127) / 128), dim3(128), 0, ST(stream), part, rows, k, scale, out, accumulate);
+  return check_launch("reduce_rows");
+}
+
+extern "C" int svae_relu_fwd(const float* x, float* y, long long n, void* stream) {
+  SVAE_REQUIRE(x && y && n > 0, SVAE_ERR_ARG, "relu_fwd: bad args");
+  hipLaunchKernelGGL(relu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, y, n);
+  return check_launch("relu_fwd");
+}
+extern "C" int svae_relu_bwd(const float* dy, const float* y, float* dx, long long n, void* stream) {
+  SVAE_REQUIRE(dy && y && dx && n > 0, SVAE_ERR_ARG, "relu_bwd: bad args");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), dy, y, dx, n);
+  return check_launch("relu_bwd");
+}
+extern "C" int svae_axpy(float a, const float* x, float* y, long long n, void* stream) {
+  SVAE_REQUIRE(x && y && n > 0, SVAE_ERR_ARG, "axpy: bad args");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), a, x, y, n);
+  return check_launch("axpy");
+}
+extern "C" int svae_fill(float* x, float v, long long n, void* stream) {
+  SVAE_REQUIRE(x && n > 0, SVAE_ERR_ARG, "fill: bad args");
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, v, n);
+  return check_launch("fill");
+}
+
+extern "C" int svae_rowloss_blocks(int rows) { return (rows + 255) / 256; }
+
+extern "C" int svae_mse_sum(const float* pred, int ld, const float* target, int ld_t, int rows, int C, float scale, float* part,
+                            float* dpred, void* stream) {
+  SVAE_REQUIRE(pred && target && part && rows > 0 && C > 0, SVAE_ERR_ARG, "mse_sum: bad args");
+  hipLaunchKernelGGL(mse_sum_kernel, dim3(svae_rowloss_blocks(rows)), dim3(256), 0, ST(stream), pred, ld, target, ld_t, rows, C,
+                     scale, part, dpred);
+  return check_launch("mse_sum");
+}
+extern "C" int svae_ce_sum(const float* logits, int ld, const int* labels, int rows, int C, float scale, float* part,
+                           float* dlogits, void* stream) {
+  SVAE_REQUIRE(logits && labels && part && rows > 0 && C > 0, SVAE_ERR_ARG, "ce_sum: bad args");
+  hipLaunchKernelGGL(ce_sum_kernel, dim3(svae_rowloss_blocks(rows)), dim3(256), 0, ST(stream), logits, ld, labels, rows, C, scale,
+                     part, dlogits);
+  return check_launch("ce_sum");
+}
+extern "C" int svae_double_softmax_ce_sum(const float* logits, int ld, int rows, float scale, float* part, float* dlogits,
+                                          void* stream) {
+  SVAE_REQUIRE(logits && part && rows > 0 && rows % 2 == 0, SVAE_ERR_ARG, "double_softmax_ce_sum: bad args");
+  hipLaunchKernelGGL(double_softmax_ce_kernel, dim3(svae_rowloss_blocks(rows)), dim3(256), 0, ST(stream), logits, ld, rows, scale,
+                     part, dlogits);
+  return check_launch("double_softmax_ce_sum");
+}

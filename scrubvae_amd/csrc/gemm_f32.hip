@@ -1,0 +1,621 @@
+// fp32 implicit-GEMM convolution kernels for gfx950 (MI355X).
+//
+// Every nn.Conv1d / nn.ConvTranspose1d / nn.Linear of the SC-VAE trunk
+// (reference: src/scrubvae/model/residual.py:79-109,137-170,198,219-222,264,286) and their
+// backward passes run through the three kernels in this file:
+//
+//   gather_gemm<BN,B_KC>  C[m][n] (+)= bias[n] + sum_t sum_c A[row(m,t)][c] * W_t[c][n]
+//        forward conv (B_KC=false: weights read as [k][n]) and data-gradient
+//        (B_KC=true: the SAME weight tensor read as [n][k]); rows are gathered per tap, so
+//        im2col never exists in memory; stride-2 transposed convs are split by output
+//        parity so no MFMA work is spent on structural zeros.
+//   wgrad_gemm<BN>        dW_t[c][n] = sum_r X[xrow(r,t)][c] * dY[yrow(r,t)][n], split over
+//        the reduction rows into slabs that are summed in a fixed order (reproducible).
+//
+// Data layout: activations channels-last [B*L][ld]; weights w[tap][c_in][c_out].
+// Math: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).
+// Tile: 128 x BN x 16 per workgroup of 4 waves (2x2), each wave 64 x BN/2 = 2 x (BN/64)
+// MFMA tiles.  K-contiguous operands sit in LDS as [row][16+4] and are fetched with one
+// ds_read_b128 per 4 k-steps: the k order inside an 8-chunk is permuted (lane half h holds
+// k = 8q+4h+j) which is legal because both operands use the same permutation.
+// Row-contiguous operands sit as [k][cols] and are fetched with conflict-free ds_read_b32.
+// Two LDS stages + register prefetch (global loads of tile k+1 are issued before the MFMAs
+// of tile k, written to LDS after them): one barrier per K tile.
+#include "svae_internal.h"
+
+namespace svae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 16;
+constexpr int LDK = BK + 4;  // padded row of a K-contiguous LDS tile (conflict-free b128)
+
+struct GatherArgs {
+  const float* A;
+  const float* W;
+  const float* bias;
+  float* C;
+  long long M[2];  // rows per phase = batch * nj[p]
+  int nj[2];
+  int ntaps[2];
+  int base[2][SVAE_MAX_TAPS];  // li = j*sj + base
+  int widx[2][SVAE_MAX_TAPS];  // weight tap of that entry
+  int blocks_m[2];
+  int Lin, Lout, sj, n_phase;
+  int Kc;  // reduction channels per tap, multiple of 16
+  int ldA, ldC, ldW;
+  long long w_tap_stride;
+  int N;  // padded output channels
+  int accumulate;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+template <int BN, bool B_KC>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
+  constexpr int WN = BN / 2;   // wave tile columns
+  constexpr int NT = WN / 32;  // MFMA tiles across
+  constexpr int B_ELEMS = B_KC ? BN * LDK : BK * BN;
+  constexpr int BPASS = BN / 64;  // float4 per thread for the B tile
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][B_ELEMS];
+  __shared__ long long rowoff[BM];
+
+  const int tid = threadIdx.x;
+  int bx = blockIdx.x, phase = 0;
+  if (bx >= g.blocks_m[0]) { phase = 1; bx -= g.blocks_m[0]; }
+  const long long m0 = (long long)bx * BM;
+  const int n0 = blockIdx.y * BN;
+  const long long Mp = g.M[phase];
+  const int nj = g.nj[phase];
+  const int ntaps = g.ntaps[phase];
+  const int* __restrict__ tap_base = g.base[phase];
+  const int* __restrict__ tap_w = g.widx[phase];
+
+  // ---- per-thread A rows (2 rows, one 16-byte column slot each)
+  const int akq = tid & 3;
+  long long a_off[2];
+  int a_j[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long long m = m0 + (tid >> 2) + 64 * i;
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      a_off[i] = b * (long long)g.Lin * g.ldA + akq * 4;
+      a_j[i] = j * g.sj;
+    } else {
+      a_off[i] = 0;
+      a_j[i] = -(1 << 28);
+    }
+  }
+  if (tid < BM) {
+    const long long m = m0 + tid;
+    long long off = -1;
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      off = (b * g.Lout + (phase + g.n_phase * j)) * (long long)g.ldC;
+    }
+    rowoff[tid] = off;
+  }
+
+  const int tiles_per_tap = g.Kc / BK;
+  const int nk = ntaps * tiles_per_tap;
+
+  float4 ra[2], rb[BPASS];
+  auto load_tile = [&](int kt) {
+    const int ti = kt / tiles_per_tap;
+    const int c0 = (kt - ti * tiles_per_tap) * BK;
+    const int tb = tap_base[ti];
+    const float* wt = g.W + (long long)tap_w[ti] * g.w_tap_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int li = a_j[i] + tb;
+      if (li >= 0 && li < g.Lin)
+        ra[i] = ld4(g.A + a_off[i] + (long long)li * g.ldA + c0);
+      else
+        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if constexpr (B_KC) {
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        const int n = n0 + (tid >> 2) + 64 * i;
+        if (n < g.N)
+          rb[i] = ld4(wt + (long long)n * g.ldW + c0 + akq * 4);
+        else
+          rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      constexpr int F4_PER_ROW = BN / 4;
+      constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+      const int n = n0 + (tid % F4_PER_ROW) * 4;
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        const int k = tid / F4_PER_ROW + ROWS_PER_PASS * i;
+        if (n < g.N)
+          rb[i] = ld4(wt + (long long)(c0 + k) * g.ldW + n);
+        else
+          rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) st4(&As[buf][((tid >> 2) + 64 * i) * LDK + akq * 4], ra[i]);
+    if constexpr (B_KC) {
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) st4(&Bs[buf][((tid >> 2) + 64 * i) * LDK + akq * 4], rb[i]);
+    } else {
+      constexpr int F4_PER_ROW = BN / 4;
+      constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i)
+        st4(&Bs[buf][(tid / F4_PER_ROW + ROWS_PER_PASS * i) * BN + (tid % F4_PER_ROW) * 4], rb[i]);
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 31, h = lane >> 5;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const float* as = As[buf];
+    const float* bs = Bs[buf];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float4 av[2], bv[NT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) av[mt] = ld4(&as[(wr * 64 + mt * 32 + lr) * LDK + q * 8 + h * 4]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (B_KC) {
+          bv[nt] = ld4(&bs[(wc * WN + nt * 32 + lr) * LDK + q * 8 + h * 4]);
+        } else {
+          const float* p = &bs[(q * 8 + h * 4) * BN + wc * WN + nt * 32 + lr];
+          bv[nt] = make_float4(p[0], p[BN], p[2 * BN], p[3 * BN]);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const float a = jj == 0 ? av[mt].x : jj == 1 ? av[mt].y : jj == 2 ? av[mt].z : av[mt].w;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const float b = jj == 0 ? bv[nt].x : jj == 1 ? bv[nt].y : jj == 2 ? bv[nt].z : bv[nt].w;
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + wc * WN + nt * 32 + lr;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long off = rowoff[row];
+        if (off >= 0) {
+          float* dst = g.C + off + col;
+          float v = acc[mt][nt][r] + bv;
+          if (g.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- weight grad
+struct WgradArgs {
+  const float* X;
+  const float* dY;
+  float* out;  // slab base [nsplit][T][Kc][ldW] or dw itself when nsplit == 1
+  long long R;  // reduction rows = batch * nj
+  long long rows_per_split;
+  long long slab_stride;
+  int nj, Lx, Ly, sx, sy;
+  int bx[SVAE_MAX_TAPS], by[SVAE_MAX_TAPS];
+  int T, Kc, N, ldX, ldY, ldW, ctiles;
+  int accumulate;
+};
+
+template <int BN>
+__global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
+  constexpr int WN = BN / 2;
+  constexpr int NT = WN / 32;
+  constexpr int BPASS = BN / 64;
+  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+  const int tid = threadIdx.x;
+  const int ti = blockIdx.x / g.ctiles;
+  const int c0 = (blockIdx.x - ti * g.ctiles) * BM;
+  const int n0 = blockIdx.y * BN;
+  const long long r_begin = (long long)blockIdx.z * g.rows_per_split;
+  long long r_end = r_begin + g.rows_per_split;
+  if (r_end > g.R) r_end = g.R;
+  const int tbx = g.bx[ti], tby = g.by[ti];
+
+  const int a_c = c0 + (tid & 31) * 4;  // 32 float4 per k-row of A
+  const int a_r = tid >> 5;             // 8 rows per pass, 2 passes
+  constexpr int F4_PER_ROW = BN / 4;
+  constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+  const int b_n = n0 + (tid % F4_PER_ROW) * 4;
+  const int b_r = tid / F4_PER_ROW;
+
+  float4 ra[2], rb[BPASS];
+  auto load_tile = [&](long long r0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long long r = r0 + a_r + 8 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < r_end && a_c < g.Kc) {
+        const long long b = r / g.nj;
+        const int j = (int)(r - b * g.nj);
+        const int xr = j * g.sx + tbx;
+        const int yr = j * g.sy + tby;
+        if (xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly) v = ld4(g.X + (b * g.Lx + xr) * (long long)g.ldX + a_c);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const long long r = r0 + b_r + ROWS_PER_PASS * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < r_end && b_n < g.N) {
+        const long long b = r / g.nj;
+        const int j = (int)(r - b * g.nj);
+        const int xr = j * g.sx + tbx;
+        const int yr = j * g.sy + tby;
+        if (xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly) v = ld4(g.dY + (b * g.Ly + yr) * (long long)g.ldY + b_n);
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) st4(&As[buf][(a_r + 8 * i) * BM + (tid & 31) * 4], ra[i]);
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) st4(&Bs[buf][(b_r + ROWS_PER_PASS * i) * BN + (tid % F4_PER_ROW) * 4], rb[i]);
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 31, h = lane >> 5;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (int)((r_end - r_begin + BK - 1) / BK);
+  if (nk > 0) {
+    load_tile(r_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(r_begin + (long long)(kt + 1) * BK);
+    const float* as = As[buf];
+    const float* bs = Bs[buf];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float av[2][4], bv[NT][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) av[mt][jj] = as[(q * 8 + h * 4 + jj) * BM + wr * 64 + mt * 32 + lr];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt][jj] = bs[(q * 8 + h * 4 + jj) * BN + wc * WN + nt * 32 + lr];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][jj], bv[nt][jj], acc[mt][nt], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* out = g.out + (long long)blockIdx.z * g.slab_stride + (long long)ti * g.Kc * g.ldW;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + wc * WN + nt * 32 + lr;
+    if (col >= g.N) continue;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (c < g.Kc) {
+          float* dst = out + (long long)c * g.ldW + col;
+          float v = acc[mt][nt][r];
+          if (g.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// dst[i] (+)= sum_s slab[s][i], fixed order
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dst,
+                                                            long long n4, long long stride, int nsplit, int accumulate) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 s = accumulate ? ld4(dst + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < nsplit; ++k) {
+      const float4 v = ld4(slab + k * stride + i * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    st4(dst + i * 4, s);
+  }
+}
+
+// column sums of a [rows][ld] matrix: part[chunk][C]
+constexpr int COLSUM_ROWS = 512;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long long rows, int C, int ld,
+                                                              float* __restrict__ part) {
+  __shared__ float red[16][65];
+  const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.y * 64 + c4 * 4;
+  const long long r0 = (long long)blockIdx.x * COLSUM_ROWS;
+  long long r1 = r0 + COLSUM_ROWS;
+  if (r1 > rows) r1 = rows;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C)
+    for (long long r = r0 + rl; r < r1; r += 16) {
+      const float4 v = ld4(x + r * ld + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[rl][c4 * 4 + 0] = s.x; red[rl][c4 * 4 + 1] = s.y; red[rl][c4 * 4 + 2] = s.z; red[rl][c4 * 4 + 3] = s.w;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+    const int cc = blockIdx.y * 64 + threadIdx.x;
+    if (cc < C) part[(long long)blockIdx.x * C + cc] = t;
+  }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < chunks; ++k) s += (double)part[(long long)k * C + c];
+  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+}
+
+// -------------------------------------------------------------------------- host side
+static int validate(const svae_conv_desc* d) {
+  SVAE_REQUIRE(d != nullptr, SVAE_ERR_ARG, "conv: null descriptor");
+  SVAE_REQUIRE(d->batch > 0 && d->l_in > 0 && d->l_out > 0, SVAE_ERR_SHAPE, "conv: non-positive batch/length");
+  SVAE_REQUIRE(d->c_in > 0 && d->c_out > 0 && d->c_in % 16 == 0 && d->c_out % 16 == 0, SVAE_ERR_SHAPE,
+               "conv: padded channel counts must be positive multiples of 16 (got %d,%d)", d->c_in, d->c_out);
+  SVAE_REQUIRE(d->ld_in >= d->c_in && d->ld_out >= d->c_out && d->ld_in % 4 == 0 && d->ld_out % 4 == 0, SVAE_ERR_ALIGN,
+               "conv: leading dimensions must be >= channels and multiples of 4");
+  SVAE_REQUIRE(d->kernel >= 1 && d->kernel <= SVAE_MAX_TAPS, SVAE_ERR_SHAPE, "conv: kernel %d not in [1,%d]", d->kernel,
+               SVAE_MAX_TAPS);
+  SVAE_REQUIRE(d->stride == 1 || d->stride == 2, SVAE_ERR_SHAPE, "conv: stride %d unsupported", d->stride);
+  SVAE_REQUIRE(d->dilation >= 1 && d->padding >= 0, SVAE_ERR_SHAPE, "conv: bad dilation/padding");
+  int expect;
+  if (!d->transposed)
+    expect = (d->l_in + 2 * d->padding - d->dilation * (d->kernel - 1) - 1) / d->stride + 1;
+  else
+    expect = (d->l_in - 1) * d->stride - 2 * d->padding + d->dilation * (d->kernel - 1) + 1;
+  SVAE_REQUIRE(expect == d->l_out, SVAE_ERR_SHAPE, "conv: l_out %d != formula %d", d->l_out, expect);
+  return SVAE_OK;
+}
+
+// Build the gather plan.  strided=true: src = j*stride + t*dil - pad (one phase);
+// strided=false: src = (dst + pad - t*dil)/stride, split by dst parity.
+static void build_plan(GatherArgs& g, const svae_conv_desc* d, bool strided, int Ldst, int Lsrc) {
+  g.Lin = Lsrc;
+  g.Lout = Ldst;
+  for (int p = 0; p < 2; ++p) { g.nj[p] = 0; g.ntaps[p] = 0; g.M[p] = 0; g.blocks_m[p] = 0; }
+  if (strided) {
+    g.n_phase = 1;
+    g.sj = d->stride;
+    g.nj[0] = Ldst;
+    g.ntaps[0] = d->kernel;
+    for (int t = 0; t < d->kernel; ++t) { g.base[0][t] = t * d->dilation - d->padding; g.widx[0][t] = t; }
+  } else {
+    const int s = d->stride;
+    g.n_phase = s;
+    g.sj = 1;
+    for (int p = 0; p < s; ++p) {
+      g.nj[p] = (Ldst - p + s - 1) / s;
+      if (g.nj[p] < 0) g.nj[p] = 0;
+      int n = 0;
+      for (int t = 0; t < d->kernel; ++t) {
+        const int num = p + d->padding - t * d->dilation;
+        if (((num % s) + s) % s != 0) continue;
+        g.base[p][n] = num / s;  // exact division
+        g.widx[p][n] = t;
+        ++n;
+      }
+      g.ntaps[p] = n;
+    }
+  }
+  for (int p = 0; p < g.n_phase; ++p) {
+    g.M[p] = (long long)d->batch * g.nj[p];
+    g.blocks_m[p] = (int)((g.M[p] + BM - 1) / BM);
+  }
+}
+
+// choose the 64-wide tile when it wastes fewer columns (e.g. N=144: 3x64=192 vs 2x128=256)
+static bool prefer_bn64(int N) {
+  const int w128 = ((N + 127) / 128) * 128, w64 = ((N + 63) / 64) * 64;
+  return w64 < w128;
+}
+
+template <bool B_KC>
+static int launch_gather_auto(GatherArgs& g, hipStream_t st) {
+  const int bm = g.blocks_m[0] + g.blocks_m[1];
+  if (bm == 0) return SVAE_OK;
+  if (prefer_bn64(g.N)) {
+    dim3 grid(bm, (g.N + 63) / 64);
+    hipLaunchKernelGGL((gather_gemm_kernel<64, B_KC>), grid, dim3(256), 0, st, g);
+  } else {
+    dim3 grid(bm, (g.N + 127) / 128);
+    hipLaunchKernelGGL((gather_gemm_kernel<128, B_KC>), grid, dim3(256), 0, st, g);
+  }
+  return check_launch("gather_gemm");
+}
+
+}  // namespace svae
+
+using namespace svae;
+
+extern "C" int svae_conv_fwd(const svae_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                             int accumulate, void* stream) {
+  if (int e = validate(d)) return e;
+  SVAE_REQUIRE(x && w && y, SVAE_ERR_ARG, "conv_fwd: null pointer");
+  SVAE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), SVAE_ERR_ALIGN, "conv_fwd: pointers must be 16-byte aligned");
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = x; g.W = w; g.bias = bias; g.C = y;
+  g.Kc = d->c_in; g.ldA = d->ld_in; g.ldC = d->ld_out; g.ldW = d->c_out;
+  g.w_tap_stride = (long long)d->c_in * d->c_out;
+  g.N = d->c_out;
+  g.accumulate = accumulate;
+  build_plan(g, d, /*strided=*/!d->transposed, d->l_out, d->l_in);
+  return launch_gather_auto<false>(g, (hipStream_t)stream);
+}
+
+extern "C" int svae_conv_dgrad(const svae_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
+                               void* stream) {
+  if (int e = validate(d)) return e;
+  SVAE_REQUIRE(dy && w && dx, SVAE_ERR_ARG, "conv_dgrad: null pointer");
+  SVAE_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx), SVAE_ERR_ALIGN, "conv_dgrad: pointers must be 16-byte aligned");
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = dy; g.W = w; g.bias = nullptr; g.C = dx;
+  g.Kc = d->c_out; g.ldA = d->ld_out; g.ldC = d->ld_in; g.ldW = d->c_out;
+  g.w_tap_stride = (long long)d->c_in * d->c_out;
+  g.N = d->c_in;
+  g.accumulate = accumulate;
+  // conv: lo = (li + pad - t*dil)/stride (fractional); convT: lo = li*stride + t*dil - pad (strided)
+  build_plan(g, d, /*strided=*/d->transposed != 0, d->l_in, d->l_out);
+  return launch_gather_auto<true>(g, (hipStream_t)stream);
+}
+
+namespace svae {
+static void wgrad_geometry(const svae_conv_desc* d, int& nsplit, long long& rps, long long& R, int& nj) {
+  nj = d->transposed ? d->l_in : d->l_out;
+  R = (long long)d->batch * nj;
+  const int bn = prefer_bn64(d->c_out) ? 64 : 128;
+  const long long tiles = (long long)d->kernel * ((d->c_in + BM - 1) / BM) * ((d->c_out + bn - 1) / bn);
+  long long want = (1536 + tiles - 1) / tiles;
+  long long maxs = (R + 255) / 256;  // at least 256 reduction rows per split
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  rps = (R + want - 1) / want;
+  rps = ((rps + BK - 1) / BK) * BK;
+  nsplit = (int)((R + rps - 1) / rps);
+}
+}  // namespace svae
+
+extern "C" size_t svae_conv_wgrad_workspace(const svae_conv_desc* d) {
+  if (validate(d)) return 0;
+  int nsplit, nj;
+  long long rps, R;
+  wgrad_geometry(d, nsplit, rps, R, nj);
+  const long long rows = (long long)d->batch * d->l_out;
+  const long long chunks = (rows + COLSUM_ROWS - 1) / COLSUM_ROWS;
+  size_t slab = nsplit > 1 ? (size_t)nsplit * d->kernel * d->c_in * d->c_out : 0;
+  return (slab + (size_t)chunks * d->c_out) * sizeof(float) + 256;
+}
+
+extern "C" int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
+                               size_t ws_bytes, int accumulate, void* stream) {
+  if (int e = validate(d)) return e;
+  SVAE_REQUIRE(x && dy && dw, SVAE_ERR_ARG, "conv_wgrad: null pointer");
+  SVAE_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(ws), SVAE_ERR_ALIGN,
+               "conv_wgrad: pointers must be 16-byte aligned");
+  SVAE_REQUIRE(ws_bytes >= svae_conv_wgrad_workspace(d), SVAE_ERR_WORKSPACE, "conv_wgrad: workspace %zu < %zu", ws_bytes,
+               svae_conv_wgrad_workspace(d));
+  hipStream_t st = (hipStream_t)stream;
+  int nsplit, nj;
+  long long rps, R;
+  wgrad_geometry(d, nsplit, rps, R, nj);
+  WgradArgs g;
+  memset(&g, 0, sizeof(g));
+  g.X = x; g.dY = dy;
+  g.R = R; g.rows_per_split = rps; g.nj = nj;
+  g.Lx = d->l_in; g.Ly = d->l_out;
+  g.T = d->kernel; g.Kc = d->c_in; g.N = d->c_out;
+  g.ldX = d->ld_in; g.ldY = d->ld_out; g.ldW = d->c_out;
+  g.ctiles = (d->c_in + BM - 1) / BM;
+  for (int t = 0; t < d->kernel; ++t) {
+    if (!d->transposed) { g.bx[t] = t * d->dilation - d->padding; g.by[t] = 0; }
+    else { g.bx[t] = 0; g.by[t] = t * d->dilation - d->padding; }
+  }
+  g.sx = d->transposed ? 1 : d->stride;
+  g.sy = d->transposed ? d->stride : 1;
+  const long long wsize = (long long)d->kernel * d->c_in * d->c_out;
+  float* slab = (float*)ws;
+  if (nsplit > 1) { g.out = slab; g.slab_stride = wsize; g.accumulate = 0; }
+  else { g.out = dw; g.slab_stride = 0; g.accumulate = accumulate; }
+  const bool bn64 = prefer_bn64(d->c_out);
+  dim3 grid(d->kernel * g.ctiles, bn64 ? (d->c_out + 63) / 64 : (d->c_out + 127) / 128, nsplit);
+  if (bn64) hipLaunchKernelGGL((wgrad_gemm_kernel<64>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((wgrad_gemm_kernel<128>), grid, dim3(256), 0, st, g);
+  if (int e = check_launch("wgrad_gemm")) return e;
+  if (nsplit > 1) {
+    const long long n4 = wsize / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slab, dw, n4, wsize, nsplit, accumulate);
+    if (int e = check_launch("reduce_slabs")) return e;
+  }
+  if (db) {
+    float* part = slab + (nsplit > 1 ? (size_t)nsplit * wsize : 0);
+    const long long rows = (long long)d->batch * d->l_out;
+    const int chunks = (int)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks, (d->c_out + 63) / 64), dim3(256), 0, st, dy, rows, d->c_out,
+                       d->ld_out, part);
+    if (int e = check_launch("colsum_partial")) return e;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d->c_out + 127) / 128), dim3(128), 0, st, part, chunks, d->c_out, db,
+                       accumulate);
+    if (int e = check_launch("colsum_final")) return e;
+  }
+  return SVAE_OK;
+}

@@ -1,0 +1,51 @@
+// Internal helpers shared by the HIP translation units of libscrubvae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "../../include/scrubvae_hip.h"
+
+namespace svae {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return SVAE_ERR_LAUNCH;
+  }
+  return SVAE_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define SVAE_REQUIRE(cond, code, ...)      \
+  do {                                     \
+    if (!(cond)) {                         \
+      svae::set_error(__VA_ARGS__);        \
+      return (code);                       \
+    }                                      \
+  } while (0)
+
+// ---- device helpers ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float* smem4) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) smem4[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = smem4[0] + smem4[1] + smem4[2] + smem4[3];
+  __syncthreads();
+  return r;
+}
+
+}  // namespace svae

@@ -1,0 +1,256 @@
+"""Thin tensor-level wrappers over the C ABI (pointers + sizes only cross the boundary).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; all arithmetic on the
+hot path happens inside libscrubvae_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+
+def pad16(c):
+    return (int(c) + 15) // 16 * 16
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t, name="tensor"):
+    if t is None:
+        return
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous float32 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+class Conv:
+    """Geometry of one nn.Conv1d / nn.ConvTranspose1d / nn.Linear call (padded channels)."""
+
+    def __init__(self, batch, l_in, c_in, c_out, kernel, stride=1, padding=0, dilation=1, transposed=False,
+                 ld_in=None, ld_out=None):
+        self.c_in_p, self.c_out_p = pad16(c_in), pad16(c_out)
+        if transposed:
+            l_out = (l_in - 1) * stride - 2 * padding + dilation * (kernel - 1) + 1
+        else:
+            l_out = (l_in + 2 * padding - dilation * (kernel - 1) - 1) // stride + 1
+        self.l_in, self.l_out, self.batch = l_in, l_out, batch
+        self.kernel = kernel
+        self.desc = ConvDesc(batch, l_in, l_out, self.c_in_p, self.c_out_p,
+                             ld_in or self.c_in_p, ld_out or self.c_out_p,
+                             kernel, stride, padding, dilation, 1 if transposed else 0)
+        self._ws_bytes = None
+
+    @property
+    def weight_shape(self):
+        return (self.kernel, self.c_in_p, self.c_out_p)
+
+    def wgrad_workspace_bytes(self):
+        if self._ws_bytes is None:
+            self._ws_bytes = int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc)))
+        return self._ws_bytes
+
+    def fwd(self, x, w, bias, y, accumulate=False):
+        check(_lib.lib().svae_conv_fwd(C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), int(accumulate), _stream()), "conv_fwd")
+        return y
+
+    def dgrad(self, dy, w, dx, accumulate=False):
+        check(_lib.lib().svae_conv_dgrad(C.byref(self.desc), _p(dy), _p(w), _p(dx), int(accumulate), _stream()), "conv_dgrad")
+        return dx
+
+    def wgrad(self, x, dy, dw, db, ws, accumulate=False):
+        check(_lib.lib().svae_conv_wgrad(C.byref(self.desc), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
+                                         ws.numel() * ws.element_size(), int(accumulate), _stream()), "conv_wgrad")
+
+
+# ----------------------------------------------------------------- weight layout (TIO)
+def conv_weight_to_tio(w, transposed=False):
+    """PyTorch Conv1d [Cout,Cin,k] / ConvTranspose1d [Cin,Cout,k] -> padded [k][Cin_p][Cout_p]."""
+    if transposed:
+        cin, cout, k = w.shape
+        t = w.permute(2, 0, 1)
+    else:
+        cout, cin, k = w.shape
+        t = w.permute(2, 1, 0)
+    out = torch.zeros(k, pad16(cin), pad16(cout), dtype=w.dtype, device=w.device)
+    out[:, :cin, :cout] = t
+    return out
+
+
+def conv_weight_from_tio(t, cin, cout, transposed=False):
+    t = t[:, :cin, :cout]
+    return (t.permute(1, 2, 0) if transposed else t.permute(2, 1, 0)).contiguous()
+
+
+def linear_weight_to_tio(w, in_perm=None, out_perm=None, in_pad=None, out_pad=None):
+    """Linear [out,in] -> [1][in_p][out_p]; in_perm/out_perm: index tensors mapping the
+    library's (channels-last) feature order to PyTorch's flatten order."""
+    out_f, in_f = w.shape
+    wt = w.t()
+    if in_perm is not None:
+        wt = wt[in_perm]
+    if out_perm is not None:
+        wt = wt[:, out_perm]
+    o = torch.zeros(1, in_pad or pad16(in_f), out_pad or pad16(out_f), dtype=w.dtype, device=w.device)
+    o[0, :in_f, :out_f] = wt
+    return o
+
+
+def linear_weight_from_tio(t, in_f, out_f, in_perm=None, out_perm=None):
+    wt = t[0, :in_f, :out_f]
+    if in_perm is not None:
+        inv = torch.empty_like(in_perm)
+        inv[in_perm] = torch.arange(in_f, device=in_perm.device)
+        wt = wt[inv]
+    if out_perm is not None:
+        inv = torch.empty_like(out_perm)
+        inv[out_perm] = torch.arange(out_f, device=out_perm.device)
+        wt = wt[:, inv]
+    return wt.t().contiguous()
+
+
+# ------------------------------------------------------------------------- elementwise
+def _arena_ptr(arena_host):
+    if arena_host is None:
+        return None
+    return (C.c_float * 6)(*[float(v) for v in arena_host])
+
+
+def pack_input(x6d, root, arena_host, out, n_joints):
+    rows = x6d.numel() // (6 * n_joints)
+    check(_lib.lib().svae_pack_input(_p(x6d), _p(root), _arena_ptr(arena_host), _p(out), rows, n_joints, out.shape[-1], _stream()), "pack_input")
+    return out
+
+
+def bn_chunks(rows):
+    return int(_lib.lib().svae_bn_chunks(rows))
+
+
+def bn_stats_partial(x, rows, Cp, ld, part):
+    check(_lib.lib().svae_bn_stats_partial(_p(x), rows, Cp, ld, _p(part), _stream()), "bn_stats_partial")
+
+
+def bn_reduce_partials(part, n_chunks, Cp, sums):
+    check(_lib.lib().svae_bn_reduce_partials(_p(part), n_chunks, Cp, _p(sums), _stream()), "bn_reduce_partials")
+
+
+def bn_finalize(sums, count, Cp, gamma, beta, eps, momentum, rmean, rvar, mean, rstd, scale, shift):
+    check(_lib.lib().svae_bn_finalize(_p(sums), float(count), Cp, _p(gamma), _p(beta), eps, momentum, _p(rmean), _p(rvar),
+                                      _p(mean), _p(rstd), _p(scale), _p(shift), _stream()), "bn_finalize")
+
+
+def bn_eval_coeffs(Cp, gamma, beta, eps, rmean, rvar, scale, shift):
+    check(_lib.lib().svae_bn_eval_coeffs(Cp, _p(gamma), _p(beta), eps, _p(rmean), _p(rvar), _p(scale), _p(shift), _stream()), "bn_eval_coeffs")
+
+
+def affine_prelu_fwd(x, scale, shift, alpha, y, rows, Cp, ld):
+    check(_lib.lib().svae_affine_prelu_fwd(_p(x), _p(scale), _p(shift), _p(alpha), _p(y), rows, Cp, ld, _stream()), "affine_prelu_fwd")
+
+
+def affine_prelu_bwd_partial(dy, x, scale, shift, mean, rstd, alpha, rows, Cp, ld, part, dalpha_part):
+    check(_lib.lib().svae_affine_prelu_bwd_partial(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(alpha), rows, Cp, ld,
+                                                   _p(part), _p(dalpha_part), _stream()), "affine_prelu_bwd_partial")
+
+
+def affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, gamma, alpha, sums, count, dx, rows, Cp, ld,
+                           dgamma, dbeta, dalpha, dalpha_part, n_chunks, accumulate):
+    check(_lib.lib().svae_affine_prelu_bwd_apply(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(gamma), _p(alpha),
+                                                 _p(sums), float(count), _p(dx), rows, Cp, ld, _p(dgamma), _p(dbeta), _p(dalpha),
+                                                 _p(dalpha_part), n_chunks, int(accumulate), _stream()), "affine_prelu_bwd_apply")
+
+
+def upsample2_fwd(x, y, batch, l_in, Cp, ld):
+    check(_lib.lib().svae_upsample2_fwd(_p(x), _p(y), batch, l_in, Cp, ld, _stream()), "upsample2_fwd")
+
+
+def upsample2_bwd(dy, dx, batch, l_in, Cp, ld, accumulate=False):
+    check(_lib.lib().svae_upsample2_bwd(_p(dy), _p(dx), batch, l_in, Cp, ld, int(accumulate), _stream()), "upsample2_bwd")
+
+
+def heads_blocks(batch, z):
+    return int(_lib.lib().svae_heads_blocks(batch, z))
+
+
+def heads_diag_fwd(h, ld, eps, mu, sigma, z, ldz, kl_part, batch, zdim):
+    check(_lib.lib().svae_heads_diag_fwd(_p(h), ld, _p(eps), _p(mu), _p(sigma), _p(z), ldz, _p(kl_part), batch, zdim, _stream()), "heads_diag_fwd")
+
+
+def heads_diag_bwd(h, ld, eps, sigma, dz, lddz, dmu, dsigma, kl_scale, dh, batch, zdim):
+    check(_lib.lib().svae_heads_diag_bwd(_p(h), ld, _p(eps), _p(sigma), _p(dz), lddz, _p(dmu), _p(dsigma), float(kl_scale), _p(dh),
+                                         batch, zdim, _stream()), "heads_diag_bwd")
+
+
+def tail_blocks(rows):
+    return int(_lib.lib().svae_tail_blocks(rows))
+
+
+def pose_tail(y, ld, offsets, target, root, arena_host, tree, jpe_scale, root_scale, ext_dx6d, ext_droot,
+              x6d_hat, root_hat, loss_part, dy, rows):
+    check(_lib.lib().svae_pose_tail(_p(y), ld, _p(offsets), _p(target), _p(root), _arena_ptr(arena_host), C.byref(tree),
+                                    float(jpe_scale), float(root_scale), _p(ext_dx6d), _p(ext_droot), _p(x6d_hat), _p(root_hat),
+                                    _p(loss_part), _p(dy), rows, _stream()), "pose_tail")
+
+
+def rot_blocks(n):
+    return int(_lib.lib().svae_rot_blocks(n))
+
+
+def rot_loss(x6d, x6d_hat, scale, part, dx6d_hat, n):
+    check(_lib.lib().svae_rot_loss(_p(x6d), _p(x6d_hat), float(scale), _p(part), _p(dx6d_hat), n, _stream()), "rot_loss")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_t, decoupled, grad_scale=1.0):
+    check(_lib.lib().svae_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step_t,
+                                    int(decoupled), grad_scale, _stream()), "adam_step")
+
+
+def sumsq_blocks(n):
+    return int(_lib.lib().svae_sumsq_blocks(n))
+
+
+def sumsq_partial(x, part):
+    check(_lib.lib().svae_sumsq_partial(_p(x), x.numel(), _p(part), _stream()), "sumsq_partial")
+
+
+def reduce_rows(part, rows, k, scale, out, accumulate=False):
+    check(_lib.lib().svae_reduce_rows(_p(part), rows, k, float(scale), _p(out), int(accumulate), _stream()), "reduce_rows")
+
+
+def relu_fwd(x, y):
+    check(_lib.lib().svae_relu_fwd(_p(x), _p(y), x.numel(), _stream()), "relu_fwd")
+
+
+def relu_bwd(dy, y, dx):
+    check(_lib.lib().svae_relu_bwd(_p(dy), _p(y), _p(dx), y.numel(), _stream()), "relu_bwd")
+
+
+def axpy(a, x, y):
+    check(_lib.lib().svae_axpy(float(a), _p(x), _p(y), x.numel(), _stream()), "axpy")
+
+
+def fill(x, v):
+    check(_lib.lib().svae_fill(_p(x), float(v), x.numel(), _stream()), "fill")
+
+
+def rowloss_blocks(rows):
+    return int(_lib.lib().svae_rowloss_blocks(rows))
+
+
+def mse_sum(pred, ld, target, ld_t, rows, Cn, scale, part, dpred):
+    check(_lib.lib().svae_mse_sum(_p(pred), ld, _p(target), ld_t, rows, Cn, float(scale), _p(part), _p(dpred), _stream()), "mse_sum")
+
+
+def ce_sum(logits, ld, labels, rows, Cn, scale, part, dlogits):
+    check(_lib.lib().svae_ce_sum(_p(logits), ld, _p(labels), rows, Cn, float(scale), _p(part), _p(dlogits), _stream()), "ce_sum")
+
+
+def double_softmax_ce_sum(logits, ld, rows, scale, part, dlogits):
+    check(_lib.lib().svae_double_softmax_ce_sum(_p(logits), ld, rows, float(scale), _p(part), _p(dlogits), _stream()), "double_softmax_ce_sum")

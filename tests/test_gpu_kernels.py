@@ -1,0 +1,329 @@
+"""Kernel-level parity on a real MI355X: every C-ABI op against the CPU oracle's op
+(stock PyTorch-CPU fp64 of the same reference call site).  Tolerances are fp32-roundoff
+scaled by the reduction length."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import scvae_oracle as O
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from scrubvae_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _ops
+
+
+def to_nlc(x_ncl, ld=None):
+    """[B,C,L] cpu -> [B*L, ld] cuda float32, zero padded."""
+    B, Cc, L = x_ncl.shape
+    ld = ld or (Cc + 15) // 16 * 16
+    out = torch.zeros(B * L, ld, dtype=torch.float32)
+    out[:, :Cc] = x_ncl.permute(0, 2, 1).reshape(B * L, Cc).float()
+    return out.cuda()
+
+
+def from_nlc(y, B, L, Cc):
+    return y.cpu()[:, :Cc].reshape(B, L, Cc).permute(0, 2, 1).double()
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+CONV_CASES = [
+    # B, L, Cin, Cout, k, stride, pad, transposed
+    (3, 64, 111, 64, 7, 1, 3, False),    # conv_in, ragged Cin
+    (5, 64, 64, 64, 5, 2, 2, False),     # res0.residual.0
+    (5, 32, 64, 128, 5, 1, 2, False),    # res0.residual.3
+    (4, 16, 256, 512, 5, 2, 2, False),   # res2.skip (N=512 -> 4 column tiles)
+    (2, 5, 40, 24, 5, 2, 2, False),      # odd length, tiny ragged channels
+    (9, 4, 128, 64, 5, 1, 2, True),      # dec residual.0 (ConvT s1)
+    (9, 4, 64, 48, 5, 2, 2, True),       # dec residual.3 (ConvT s2: 4 -> 7, parity split)
+    (3, 13, 32, 32, 5, 2, 2, True),      # 13 -> 25
+    (7, 8, 128, 64, 6, 1, 2, False),     # skip conv after upsample (k+1, even kernel)
+    (2, 49, 64, 141, 22, 1, 3, True),    # conv_out: N=141 -> padded 144, 3 x BN=64
+    (200, 1, 512, 64, 1, 1, 0, False),   # Linear as 1x1 conv, M=200
+    (33, 1, 40, 4096, 1, 1, 0, False),   # fc_in-like, wide N
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(ops, case):
+    B, L, Cin, Cout, k, s, p, tr = case
+    g = torch.Generator().manual_seed(sum(case[:7]))
+    x = torch.randn(B, Cin, L, generator=g, dtype=torch.float64)
+    w = torch.randn(*((Cin, Cout, k) if tr else (Cout, Cin, k)), generator=g, dtype=torch.float64) / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    x.requires_grad_(True); w.requires_grad_(True); b.requires_grad_(True)
+    y = (F.conv_transpose1d if tr else F.conv1d)(x, w, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    Lout = y.shape[-1]
+
+    cv = ops.Conv(B, L, Cin, Cout, k, s, p, 1, tr)
+    assert cv.l_out == Lout
+    xd = to_nlc(x.detach())
+    wd = ops.conv_weight_to_tio(w.detach().float(), tr).cuda().contiguous()
+    bd = torch.zeros(cv.c_out_p); bd[:Cout] = b.detach().float(); bd = bd.cuda()
+    yd = torch.full((B * Lout, cv.c_out_p), float("nan"), device="cuda")
+    cv.fwd(xd, wd, bd, yd)
+    torch.cuda.synchronize()
+    tol = 2e-6 * math.sqrt(Cin * k) + 2e-6
+    assert relerr(from_nlc(yd, B, Lout, Cout), y.detach()) < tol
+    assert float(yd[:, Cout:].abs().max() if cv.c_out_p > Cout else 0) == 0.0  # pads stay zero
+    # accumulate
+    cv.fwd(xd, wd, bd, yd, accumulate=True)
+    assert relerr(from_nlc(yd, B, Lout, Cout), 2 * y.detach()) < tol
+
+    dyd = to_nlc(dy)
+    dxd = torch.full((B * L, cv.c_in_p), float("nan"), device="cuda")
+    cv.dgrad(dyd, wd, dxd)
+    assert relerr(from_nlc(dxd, B, L, Cin), x.grad) < 2e-6 * math.sqrt(Cout * k) + 2e-6
+
+    ws = torch.empty(cv.wgrad_workspace_bytes() // 4 + 4, device="cuda")
+    dwd = torch.full(cv.weight_shape, float("nan"), device="cuda")
+    dbd = torch.full((cv.c_out_p,), float("nan"), device="cuda")
+    cv.wgrad(xd, dyd, dwd, dbd, ws)
+    dw = ops.conv_weight_from_tio(dwd.cpu(), Cin, Cout, tr)
+    assert relerr(dw, w.grad) < 2e-6 * math.sqrt(B * Lout) + 2e-6
+    assert relerr(dbd.cpu()[:Cout], b.grad) < 2e-6 * math.sqrt(B * Lout) + 2e-6
+    cv.wgrad(xd, dyd, dwd, dbd, ws, accumulate=True)
+    assert relerr(ops.conv_weight_from_tio(dwd.cpu(), Cin, Cout, tr), 2 * w.grad) < 2e-6 * math.sqrt(B * Lout) + 2e-6
+
+
+def test_conv_rejects_bad_shapes(ops):
+    cv = ops.Conv(2, 8, 16, 16, 5, 2, 2)
+    cv.desc.l_out = 99
+    x = torch.zeros(16, 16, device="cuda")
+    with pytest.raises(RuntimeError, match="l_out"):
+        cv.fwd(x, x, None, x)
+
+
+def test_pack_input(ops):
+    B, W, J = 3, 8, 18
+    x6d = torch.randn(B, W, J, 6)
+    root = torch.rand(B, W, 3) * 4 - 1
+    arena = [-1.0, -2.0, -0.5, 3.0, 2.0, 1.5]
+    out = torch.full((B * W, 112), float("nan"), device="cuda")
+    ops.pack_input(x6d.cuda(), root.cuda(), arena, out, J)
+    a = torch.tensor(arena).reshape(2, 3)
+    ref = torch.cat([x6d.reshape(B * W, -1), O.normalize_root(root, a).reshape(B * W, 3)], -1)
+    assert relerr(out.cpu()[:, :111], ref) < 1e-6
+    assert float(out[:, 111:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,Cc", [(700, 48), (4096, 144), (37, 16)])
+def test_bn_prelu_fwd_bwd(ops, rows, Cc):
+    """Train-mode BatchNorm1d(eps=1e-4)+PReLU forward/backward vs torch CPU fp64."""
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, Cc, generator=g, dtype=torch.float64) * 2 + 0.7).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(Cc, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.1 * torch.randn(Cc, generator=g, dtype=torch.float64)).requires_grad_(True)
+    alpha = torch.tensor([0.25], dtype=torch.float64, requires_grad=True)
+    rm, rv = torch.zeros(Cc, dtype=torch.float64), torch.ones(Cc, dtype=torch.float64)
+    # torch wants [N,C]; BatchNorm over rows
+    y = F.prelu(F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-4), alpha)
+    dy = torch.randn(rows, Cc, generator=g, dtype=torch.float64)
+    y.backward(dy)
+
+    dev = lambda t: t.detach().float().cuda().contiguous()
+    xd, gd, bd, ad = dev(x), dev(gamma), dev(beta), dev(alpha)
+    nch = ops.bn_chunks(rows)
+    part = torch.empty(nch, 2, Cc, device="cuda")
+    sums = torch.empty(2, Cc, device="cuda")
+    rmd, rvd = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    mean, rstd, scale, shift = (torch.empty(Cc, device="cuda") for _ in range(4))
+    ops.bn_stats_partial(xd, rows, Cc, Cc, part)
+    ops.bn_reduce_partials(part, nch, Cc, sums)
+    ops.bn_finalize(sums, rows, Cc, gd, bd, 1e-4, 0.1, rmd, rvd, mean, rstd, scale, shift)
+    yd = torch.empty_like(xd)
+    ops.affine_prelu_fwd(xd, scale, shift, ad, yd, rows, Cc, Cc)
+    assert relerr(yd.cpu(), y.detach()) < 5e-6
+    assert relerr(rmd.cpu(), rm) < 5e-6 and relerr(rvd.cpu(), rv) < 5e-6
+
+    dyd = dev(dy)
+    dap = torch.empty(nch * ((Cc + 63) // 64), device="cuda")
+    ops.affine_prelu_bwd_partial(dyd, xd, scale, shift, mean, rstd, ad, rows, Cc, Cc, part, dap)
+    ops.bn_reduce_partials(part, nch, Cc, sums)
+    dxd = torch.empty_like(xd)
+    dg, db, da = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda"), torch.zeros(1, device="cuda")
+    ops.affine_prelu_bwd_apply(dyd, xd, scale, shift, mean, rstd, gd, ad, sums, rows, dxd, rows, Cc, Cc, dg, db, da, dap, nch, False)
+    assert relerr(dxd.cpu(), x.grad) < 2e-5
+    assert relerr(dg.cpu(), gamma.grad) < 2e-5 and relerr(db.cpu(), beta.grad) < 2e-5
+    assert relerr(da.cpu(), alpha.grad) < 2e-5
+
+
+def test_bare_prelu_bwd(ops):
+    rows, Cc = 300, 64
+    x = torch.randn(rows, Cc, dtype=torch.float64, requires_grad=True)
+    alpha = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+    y = F.prelu(x, alpha)
+    dy = torch.randn(rows, Cc, dtype=torch.float64)
+    y.backward(dy)
+    dev = lambda t: t.detach().float().cuda().contiguous()
+    xd, ad, dyd = dev(x), dev(alpha), dev(dy)
+    yd = torch.empty_like(xd)
+    ops.affine_prelu_fwd(xd, None, None, ad, yd, rows, Cc, Cc)
+    assert relerr(yd.cpu(), y.detach()) < 1e-6
+    nch = ops.bn_chunks(rows)
+    part = torch.empty(nch, 2, Cc, device="cuda")
+    dap = torch.empty(nch, device="cuda")
+    ops.affine_prelu_bwd_partial(dyd, xd, None, None, None, None, ad, rows, Cc, Cc, part, dap)
+    dxd = torch.empty_like(xd)
+    da = torch.zeros(1, device="cuda")
+    ops.affine_prelu_bwd_apply(dyd, xd, None, None, None, None, None, ad, None, 1.0, dxd, rows, Cc, Cc, None, None, da, dap, nch, False)
+    assert relerr(dxd.cpu(), x.grad) < 1e-6 and relerr(da.cpu(), alpha.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,L,Cc", [(3, 4, 32), (2, 7, 16), (5, 1, 16)])
+def test_upsample2(ops, B, L, Cc):
+    x = torch.randn(B, Cc, L, dtype=torch.float64, requires_grad=True)
+    y = F.interpolate(x, scale_factor=2, mode="linear", align_corners=False)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    xd = to_nlc(x.detach())
+    yd = torch.empty(B * 2 * L, Cc, device="cuda")
+    ops.upsample2_fwd(xd, yd, B, L, Cc, Cc)
+    assert relerr(from_nlc(yd, B, 2 * L, Cc), y.detach()) < 1e-6
+    dxd = torch.empty(B * L, Cc, device="cuda")
+    ops.upsample2_bwd(to_nlc(dy), dxd, B, L, Cc, Cc)
+    assert relerr(from_nlc(dxd, B, L, Cc), x.grad) < 1e-6
+
+
+def test_heads_diag(ops):
+    B, z = 37, 8
+    h = torch.randn(B, 2 * z, dtype=torch.float64, requires_grad=True)
+    eps = torch.randn(B, z, dtype=torch.float64)
+    mu, raw = h[:, :z], h[:, z:]
+    L = O.cholesky_L(raw, z, True)
+    zz = torch.matmul(L, eps[..., None]).squeeze(-1) + mu
+    kl = O.prior_loss(mu, L)
+    dz = torch.randn(B, z, dtype=torch.float64)
+    (0.7 * kl + (zz * dz).sum()).backward()
+    hd = torch.zeros(B, 16, device="cuda"); hd[:, :2 * z] = h.detach().float().cuda()
+    mud, sd, zd = torch.empty(B, z, device="cuda"), torch.empty(B, z, device="cuda"), torch.zeros(B, 16, device="cuda")
+    klp = torch.empty(ops.heads_blocks(B, z), device="cuda")
+    ops.heads_diag_fwd(hd, 16, eps.float().cuda(), mud, sd, zd, 16, klp, B, z)
+    assert relerr(zd.cpu()[:, :z], zz.detach()) < 1e-6
+    assert relerr(sd.cpu(), L.diagonal(dim1=-2, dim2=-1).detach()) < 1e-6
+    assert abs(float(klp.sum()) / B - float(kl)) < 1e-5 * abs(float(kl))
+    dh = torch.zeros(B, 16, device="cuda")
+    dzd = torch.zeros(B, 16, device="cuda"); dzd[:, :z] = dz.float().cuda()
+    ops.heads_diag_bwd(hd, 16, eps.float().cuda(), sd, dzd, 16, None, None, 0.7 / B, dh, B, z)
+    assert relerr(dh.cpu()[:, :2 * z], h.grad) < 2e-6
+
+
+@pytest.mark.parametrize("J", [18, 23])
+def test_pose_tail(ops, J):
+    """tanh + unpack + FK + JPE/root sums + analytic backward vs autograd on the oracle."""
+    from scrubvae_amd._lib import make_tree
+    tree = O.skeleton_tree(J)
+    B, W = 3, 50  # 150 rows: 2 full blocks + a ragged one
+    rows = B * W
+    C6 = 6 * J
+    ld = (C6 + 3 + 15) // 16 * 16
+    g = torch.Generator().manual_seed(J)
+    y = torch.randn(rows, ld, generator=g, dtype=torch.float64)
+    y[:, C6 + 3:] = 0
+    y.requires_grad_(True)
+    arena = torch.tensor([[-1.0, -2.0, -0.5], [3.0, 2.0, 1.5]], dtype=torch.float64)
+    offsets = torch.randn(rows, J, 3, generator=g, dtype=torch.float64)
+    target = torch.randn(rows, J, 3, generator=g, dtype=torch.float64)
+    root = torch.randn(rows, 3, generator=g, dtype=torch.float64)
+    xh = torch.tanh(y)
+    x6d = xh[:, :C6].reshape(rows, J, 6)
+    root_hat = O.inv_normalize_root(xh[:, C6:C6 + 3], arena)
+    pose = O.fwd_kin(x6d, tree, offsets, torch.zeros(rows, 3, dtype=torch.float64), eps=1e-8)
+    jpe = ((target - pose) ** 2).sum()
+    rl = ((root_hat - root) ** 2).sum()
+    (0.37 * jpe + 1.3 * rl).backward()
+
+    dev = lambda t: t.detach().float().cuda().contiguous()
+    nb = ops.tail_blocks(rows)
+    x6o, ro = torch.empty(rows, C6, device="cuda"), torch.empty(rows, 3, device="cuda")
+    lp = torch.empty(nb, 2, device="cuda")
+    dy = torch.full((rows, ld), float("nan"), device="cuda")
+    ops.pose_tail(dev(y), ld, dev(offsets), dev(target), dev(root), arena.flatten().tolist(), make_tree(J, tree),
+                  0.37, 1.3, None, None, x6o, ro, lp, dy, rows)
+    assert relerr(x6o.cpu(), x6d.detach().reshape(rows, C6)) < 2e-6
+    assert relerr(ro.cpu(), root_hat.detach()) < 2e-6
+    s = lp.double().sum(0).cpu()
+    assert abs(float(s[0]) - float(jpe)) < 2e-5 * float(jpe)
+    assert abs(float(s[1]) - float(rl)) < 2e-5 * float(rl)
+    assert relerr(dy.cpu(), y.grad) < 5e-4  # ill-conditioned normalisations: fp32 floor ~1e-4
+    # eval form: no gradient buffer
+    ops.pose_tail(dev(y), ld, dev(offsets), dev(target), dev(root), arena.flatten().tolist(), make_tree(J, tree),
+                  0.0, 0.0, None, None, x6o, ro, lp, None, rows)
+    assert abs(float(lp.double().sum(0)[0]) - float(jpe)) < 2e-5 * float(jpe)
+
+
+def test_rot_loss(ops):
+    n = 1000
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 6, generator=g, dtype=torch.float64)
+    xh = (x + 0.3 * torch.randn(n, 6, generator=g, dtype=torch.float64)).requires_grad_(True)  # well-conditioned
+    loss = O.stable_rotation_loss(x, xh)
+    loss.backward()
+    part = torch.empty(ops.rot_blocks(n), device="cuda")
+    dxh = torch.empty(n, 6, device="cuda")
+    ops.rot_loss(x.float().cuda(), xh.detach().float().cuda(), 1.0, part, dxh, n)
+    assert abs(float(part.double().sum()) - float(loss)) < 1e-5 * float(loss)
+    assert relerr(dxh.cpu(), xh.grad) < 1e-3
+
+
+def test_adam_and_norm(ops):
+    n = 4096 + 64
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(n, generator=g)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    pd, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for t in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        p.grad = gr.clone()
+        opt.step()
+        ops.adam_step(pd, gr.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, t, True)
+    assert relerr(pd.cpu(), p.detach()) < 1e-6
+    part = torch.empty(ops.sumsq_blocks(n), device="cuda")
+    ops.sumsq_partial(pd, part)
+    out = torch.zeros(1, device="cuda")
+    ops.reduce_rows(part, part.numel(), 1, 1.0, out)
+    assert abs(float(out) - float((pd.double() ** 2).sum())) < 1e-5 * float(out)
+
+
+def test_small_losses(ops):
+    rows, Cn = 300, 3
+    g = torch.Generator().manual_seed(2)
+    pred = torch.randn(rows, Cn, generator=g, dtype=torch.float64, requires_grad=True)
+    tgt = torch.randn(rows, Cn, generator=g, dtype=torch.float64)
+    l = ((pred - tgt) ** 2).sum(); (0.5 * l).backward()
+    pd = torch.zeros(rows, 16, device="cuda"); pd[:, :Cn] = pred.detach().float().cuda()
+    part = torch.empty(ops.rowloss_blocks(rows), device="cuda")
+    dp = torch.zeros(rows, 16, device="cuda")
+    ops.mse_sum(pd, 16, tgt.float().cuda().contiguous(), Cn, rows, Cn, 0.5, part, dp)
+    assert abs(float(part.double().sum()) - float(l)) < 1e-5 * float(l)
+    assert relerr(dp.cpu()[:, :Cn], pred.grad) < 1e-6
+    # CE on integer labels
+    logits = torch.randn(rows, 4, generator=g, dtype=torch.float64, requires_grad=True)
+    lab = torch.randint(0, 4, (rows,), generator=g)
+    l = F.cross_entropy(logits, lab, reduction="sum"); l.backward()
+    ld_ = torch.zeros(rows, 16, device="cuda"); ld_[:, :4] = logits.detach().float().cuda()
+    dl = torch.zeros(rows, 16, device="cuda")
+    ops.ce_sum(ld_, 16, lab.int().cuda(), rows, 4, 1.0, part, dl)
+    assert abs(float(part.double().sum()) - float(l)) < 1e-5 * float(l)
+    assert relerr(dl.cpu()[:, :4], logits.grad) < 2e-6
+    # double softmax CE (adversarial-net quirk)
+    logits = torch.randn(rows, 2, generator=g, dtype=torch.float64, requires_grad=True)
+    yoh = F.one_hot((torch.arange(rows) >= rows // 2).long(), 2).double()
+    l = F.cross_entropy(torch.softmax(logits, -1), yoh, reduction="sum"); (-0.25 * l).backward()
+    ld_ = torch.zeros(rows, 16, device="cuda"); ld_[:, :2] = logits.detach().float().cuda()
+    dl = torch.zeros(rows, 16, device="cuda")
+    ops.double_softmax_ce_sum(ld_, 16, rows, -0.25, part, dl)
+    assert abs(float(part.double().sum()) - float(l)) < 1e-5 * float(l)
+    assert relerr(dl.cpu()[:, :2], logits.grad) < 2e-6
