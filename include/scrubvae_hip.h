@@ -127,18 +127,18 @@ int svae_upsample2_bwd(const float* dy, float* dx, int batch, int l_in, int C, i
                        void* stream);
 
 /* ------------------------------------------------------------------- latent heads --- */
-/* E4+S1+L3 (diag): h [B, ld] = [mu | raw]; sigma = softplus(raw) (residual.py:60-68),
+/* E4+S1+L3 (diag): mu/sigma/dmu/dsigma are [B, ldm] (ldm >= z); eps is [B, z]; h [B, ld]: mu at columns [0,z), raw at [raw_off, raw_off+z); sigma = softplus(raw) (residual.py:60-68),
  * z = mu + sigma*eps (residual.py:305-316; eps NULL => z = mu, eval mode),
  * kl_part[blocks] = per-block partial of -0.5*sum(1+2log(sigma)-mu^2-sigma^2)
  * (losses.py:138-146, before the /B). */
 int svae_heads_diag_fwd(const float* h, int ld, const float* eps, float* mu, float* sigma, float* z,
-                        int ldz, float* kl_part, int batch, int zdim, void* stream);
+                        int ldz, float* kl_part, int batch, int zdim, int raw_off, int ldm, void* stream);
 int svae_heads_blocks(int batch, int zdim);
 /* dh = [dmu_total | draw]: dmu_total = dmu + dz + kl_scale*mu,
  * draw = (dz*eps + dsigma + kl_scale*(sigma-1/sigma)) * sigmoid(raw). */
 int svae_heads_diag_bwd(const float* h, int ld, const float* eps, const float* sigma,
                         const float* dz, int lddz, const float* dmu, const float* dsigma, float kl_scale,
-                        float* dh, int batch, int zdim, void* stream);
+                        float* dh, int batch, int zdim, int raw_off, int ldm, void* stream);
 
 /* ----------------------------------------------------------------- pose-loss tail --- */
 typedef struct {
@@ -158,6 +158,8 @@ typedef struct {
  *   dy [rows, ld] = jpe_scale * d jpe_sum/dy + root_scale * d root_sum/dy   (analytic
  *   reverse-mode through the kinematic chains, the 6D->matrix map and tanh).
  * `arena` is a HOST pointer to 6 floats (NULL: no root channels).
+ * input_is_pre_tanh = 0: `y` already holds x_hat (no tanh, dy = d/dx_hat): the stand-alone
+ * mpjpe_loss form.
  * loss_part [blocks][2].  dy may be NULL (eval: forward only).  ext_dx6d/ext_droot
  * (optional) are extra upstream grads w.r.t. x6d_hat/root_hat added before the tanh
  * backward (used by the rotation loss and by autograd callers). */
@@ -166,7 +168,7 @@ int svae_pose_tail(const float* y, int ld, const float* offsets, const float* ta
                    const float* root, const float* arena, const svae_tree* tree,
                    float jpe_scale, float root_scale, const float* ext_dx6d, const float* ext_droot,
                    float* x6d_hat, float* root_hat, float* loss_part, float* dy,
-                   long long rows, void* stream);
+                   long long rows, int input_is_pre_tanh, void* stream);
 
 /* L4: stable_rotation_loss (losses.py:123-136, rotation_conversion.py:469-488):
  * part[blocks] partial sums of 2*asin(clamp(|R(x_hat)-R(x)|_F/2^1.5)); dx6d_hat (optional)

@@ -273,16 +273,16 @@ __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log
 __global__ __launch_bounds__(256) void heads_diag_fwd_kernel(const float* __restrict__ h, int ld, const float* __restrict__ eps,
                                                               float* __restrict__ mu, float* __restrict__ sigma,
                                                               float* __restrict__ z, int ldz, float* __restrict__ kl_part, int batch,
-                                                              int zd) {
+                                                              int zd, int raw_off, int ldm) {
   __shared__ float red4[4];
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   float kl = 0.f;
   if (i < (long long)batch * zd) {
     const int b = (int)(i / zd), k = (int)(i - (long long)b * zd);
     const float m = h[(long long)b * ld + k];
-    const float s = softplus_f(h[(long long)b * ld + zd + k]);
-    mu[i] = m;
-    sigma[i] = s;
+    const float s = softplus_f(h[(long long)b * ld + raw_off + k]);
+    mu[(long long)b * ldm + k] = m;
+    sigma[(long long)b * ldm + k] = s;
     z[(long long)b * ldz + k] = eps ? m + s * eps[i] : m;
     kl = -0.5f * (1.f + 2.f * logf(s) - m * m - s * s);
   }
@@ -293,21 +293,21 @@ __global__ __launch_bounds__(256) void heads_diag_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void heads_diag_bwd_kernel(const float* __restrict__ h, int ld, const float* __restrict__ eps,
                                                               const float* __restrict__ sigma, const float* __restrict__ dz, int lddz,
                                                               const float* __restrict__ dmu, const float* __restrict__ dsigma,
-                                                              float kl_scale, float* __restrict__ dh, int batch, int zd) {
+                                                              float kl_scale, float* __restrict__ dh, int batch, int zd, int raw_off, int ldm) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)batch * zd) return;
   const int b = (int)(i / zd), k = (int)(i - (long long)b * zd);
-  const float m = h[(long long)b * ld + k], raw = h[(long long)b * ld + zd + k];
-  const float s = sigma[i];
+  const float m = h[(long long)b * ld + k], raw = h[(long long)b * ld + raw_off + k];
+  const float s = sigma[(long long)b * ldm + k];
   const float gz = dz ? dz[(long long)b * lddz + k] : 0.f;
   float gm = gz + kl_scale * m;
-  if (dmu) gm += dmu[i];
+  if (dmu) gm += dmu[(long long)b * ldm + k];
   float gs = kl_scale * (s - 1.f / s);
   if (eps) gs += gz * eps[i];
-  if (dsigma) gs += dsigma[i];
+  if (dsigma) gs += dsigma[(long long)b * ldm + k];
   const float sig = 1.f / (1.f + expf(-raw));
   dh[(long long)b * ld + k] = gm;
-  dh[(long long)b * ld + zd + k] = gs * sig;
+  dh[(long long)b * ld + raw_off + k] = gs * sig;
 }
 
 // -------------------------------------------------------------------------- optimizer
@@ -544,20 +544,20 @@ extern "C" int svae_upsample2_bwd(const float* dy, float* dx, int batch, int l_i
 extern "C" int svae_heads_blocks(int batch, int zdim) { return (int)(((long long)batch * zdim + 255) / 256); }
 
 extern "C" int svae_heads_diag_fwd(const float* h, int ld, const float* eps, float* mu, float* sigma, float* z, int ldz,
-                                   float* kl_part, int batch, int zdim, void* stream) {
-  SVAE_REQUIRE(h && mu && sigma && z && kl_part && batch > 0 && zdim > 0 && ld >= 2 * zdim && ldz >= zdim, SVAE_ERR_ARG,
+                                   float* kl_part, int batch, int zdim, int raw_off, int ldm, void* stream) {
+  SVAE_REQUIRE(h && mu && sigma && z && kl_part && batch > 0 && zdim > 0 && raw_off >= zdim && ld >= raw_off + zdim && ldz >= zdim, SVAE_ERR_ARG,
                "heads_diag_fwd: bad args");
   hipLaunchKernelGGL(heads_diag_fwd_kernel, dim3(svae_heads_blocks(batch, zdim)), dim3(256), 0, ST(stream), h, ld, eps, mu, sigma,
-                     z, ldz, kl_part, batch, zdim);
+                     z, ldz, kl_part, batch, zdim, raw_off, ldm);
   return check_launch("heads_diag_fwd");
 }
 
 extern "C" int svae_heads_diag_bwd(const float* h, int ld, const float* eps, const float* sigma, const float* dz, int lddz,
                                    const float* dmu, const float* dsigma, float kl_scale, float* dh, int batch, int zdim,
-                                   void* stream) {
+                                   int raw_off, int ldm, void* stream) {
   SVAE_REQUIRE(h && sigma && dh && batch > 0 && zdim > 0, SVAE_ERR_ARG, "heads_diag_bwd: bad args");
   hipLaunchKernelGGL(heads_diag_bwd_kernel, dim3(svae_heads_blocks(batch, zdim)), dim3(256), 0, ST(stream), h, ld, eps, sigma, dz,
-                     lddz, dmu, dsigma, kl_scale, dh, batch, zdim);
+                     lddz, dmu, dsigma, kl_scale, dh, batch, zdim, raw_off, ldm);
   return check_launch("heads_diag_bwd");
 }
 

@@ -29,6 +29,7 @@ struct TailArgs {
   long long rows;
   int ld, J, ldt, ldo;
   int has_arena;
+  int pre_tanh;
   float a0[3], a1[3];
   float jpe_scale, root_scale;
   svae_tree tree;
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(64) void pose_tail_kernel(const TailArgs g) {
       const int rr = e / f4_per_row, c = (e - rr * f4_per_row) * 4;
       const float4 v = *reinterpret_cast<const float4*>(src + (long long)e * 4);
       float* d = tile + rr * ldt + c;
-      d[0] = tanhf(v.x); d[1] = tanhf(v.y); d[2] = tanhf(v.z); d[3] = tanhf(v.w);
+      if (g.pre_tanh) { d[0] = tanhf(v.x); d[1] = tanhf(v.y); d[2] = tanhf(v.z); d[3] = tanhf(v.w); }
+      else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
     }
     const int tot3 = nrows * J3;
     const float* so = g.offsets + r0 * J3;
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(64) void pose_tail_kernel(const TailArgs g) {
             for (int k = 0; k < 6; ++k) {
               float gk = da[k];
               if (g.ext_dx6d) gk += g.ext_dx6d[(r0 + lane) * C6 + 6 * j + k];
-              my[6 * j + k] = gk * (1.f - a6[k] * a6[k]);
+              my[6 * j + k] = g.pre_tanh ? gk * (1.f - a6[k] * a6[k]) : gk;
             }
           }
         }
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(64) void pose_tail_kernel(const TailArgs g) {
       for (int k = 0; k < 6; ++k) {
         float gk = da0[k];
         if (g.ext_dx6d) gk += g.ext_dx6d[(r0 + lane) * C6 + k];
-        my[k] = gk * (1.f - a0[k] * a0[k]);
+        my[k] = g.pre_tanh ? gk * (1.f - a0[k] * a0[k]) : gk;
       }
     }
     if (g.has_arena) {
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(64) void pose_tail_kernel(const TailArgs g) {
         if (do_bwd) {
           float gk = 2.f * g.root_scale * d;
           if (g.ext_droot) gk += g.ext_droot[(r0 + lane) * 3 + k];
-          my[C6 + k] = gk * half * (1.f - xh * xh);
+          my[C6 + k] = g.pre_tanh ? gk * half * (1.f - xh * xh) : gk * half;
         }
       }
     }
@@ -425,7 +427,7 @@ extern "C" int svae_tail_blocks(long long rows) { return (int)((rows + 63) / 64)
 extern "C" int svae_pose_tail(const float* y, int ld, const float* offsets, const float* target_pose, const float* root,
                               const float* arena_host, const svae_tree* tree, float jpe_scale, float root_scale,
                               const float* ext_dx6d, const float* ext_droot, float* x6d_hat, float* root_hat, float* loss_part,
-                              float* dy, long long rows, void* stream) {
+                              float* dy, long long rows, int input_is_pre_tanh, void* stream) {
   SVAE_REQUIRE(y && offsets && target_pose && tree && x6d_hat && loss_part && rows > 0, SVAE_ERR_ARG, "pose_tail: null pointer");
   const int J = tree->n_joints;
   SVAE_REQUIRE(J >= 1 && J <= SVAE_MAX_JOINTS && tree->n_chains >= 0 && tree->n_chains <= SVAE_MAX_CHAINS, SVAE_ERR_SHAPE,
@@ -455,6 +457,7 @@ extern "C" int svae_pose_tail(const float* y, int ld, const float* offsets, cons
   g.ldt = ld | 1;
   g.ldo = (3 * J) | 1;
   g.has_arena = arena_host != nullptr;
+  g.pre_tanh = input_is_pre_tanh;
   if (arena_host)
     for (int k = 0; k < 3; ++k) { g.a0[k] = arena_host[k]; g.a1[k] = arena_host[3 + k]; }
   g.jpe_scale = jpe_scale; g.root_scale = root_scale;

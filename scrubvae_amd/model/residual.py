@@ -1,0 +1,692 @@
+"""MI355X-native ResVAE: the reference's module tree and Python API
+(src/scrubvae/model/residual.py:183-491) over the HIP kernels of libscrubvae_hip.so.
+
+``ResVAE.forward(data) -> data_o`` / ``encode`` / ``decode`` keep the reference's dict
+contract.  Underneath, the trunk is an explicit kernel schedule:
+
+  forward : pack -> conv_in -> [conv|conv -> BN-stats -> BN+PReLU -> conv(+=) -> BN+PReLU] x4
+            -> fc_mu, fc_sigma -> heads(softplus, z = mu + sigma*eps, KL partials)
+            -> fc_in -> [convT -> BN+PReLU -> convT ; upsample -> conv(+=) -> BN+PReLU] x4
+            -> conv_out -> fused tanh/unpack/FK/JPE/root tail
+  backward: the hand-written reverse schedule (``backward_from_seeds``), gradients land in
+            one flat buffer that every ``param.grad`` is a view of.
+
+Activations are channels-last [B*L, Cp] so the reference's moveaxis copies vanish and
+every conv is an implicit GEMM over contiguous rows.  There is no autograd graph through
+the trunk: ``get_batch_loss`` (train/losses.py) returns a ``total`` whose ``.backward()``
+runs the reverse schedule.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..ops import pad16
+from .._lib import make_tree
+from .layers import ConvP, LinearP, BatchNormP, PReLUP, Marker, Leaf
+from .disentangle import GRScrubber, AdvNetScrubber, MLPEnsemble, EnsembleRunner
+
+
+def find_latent_dim(window_size, kernel, num_layers, dilation=None):
+    """residual.py:6-20 -- float division per layer, one int() at the end (quirk kept)."""
+    dil = [1] * num_layers if dilation is None else [int(d) for d in dilation]
+    stride = 1 if any(d > 1 for d in dil) else 2
+    l_out = window_size
+    for i in range(num_layers):
+        l_out = (l_out + 2 * (kernel // 2) - dil[i] * (kernel - 1) - 1) / stride + 1
+    return int(l_out)
+
+
+def find_out_dim(latent_dim, kernel, num_layers, dilation=None):
+    """residual.py:23-36 (indexes dilation[-i] with i from 0: quirk kept)."""
+    dil = [1] * num_layers if dilation is None else [int(d) for d in dilation]
+    stride = 1 if any(d > 1 for d in dil) else 2
+    l_out = latent_dim
+    for i in range(num_layers):
+        l_out = (l_out - 1) * stride - 2 * (kernel // 2) + dil[-i] * (kernel - 1) + 1
+    return int(l_out)
+
+
+class ResidualBlock(nn.Module):
+    """residual.py:71-119: skip Conv1d(s=2) || [Conv1d(s=2) -> BN -> PReLU -> Conv1d] ; add ; BN ; PReLU."""
+
+    def __init__(self, in_channels, out_channels, kernel=3, activation="prelu", dilation=1):
+        super().__init__()
+        if activation != "prelu":
+            raise NotImplementedError("scrubvae_amd implements activation='prelu' (the reference default)")
+        if dilation != 1:
+            raise NotImplementedError("init_dilation is not supported by the HIP trunk yet")
+        self.residual = nn.Sequential(
+            ConvP(in_channels, out_channels // 2, kernel, 2, kernel // 2),
+            BatchNormP(out_channels // 2), PReLUP(),
+            ConvP(out_channels // 2, out_channels, kernel, 1, kernel // 2))
+        self.skip = ConvP(in_channels, out_channels, kernel, 2, kernel // 2)
+        self.add = nn.Sequential(BatchNormP(out_channels), PReLUP())
+
+
+class ResidualBlockTranspose(nn.Module):
+    """residual.py:122-180: skip [Upsample x2 -> Conv1d(k+1)] || [ConvT(s=1) -> BN -> PReLU -> ConvT(s=2)]."""
+
+    def __init__(self, in_channels, out_channels, kernel=3, scale_factor=2, activation="prelu", dilation=1):
+        super().__init__()
+        if activation != "prelu" or dilation != 1 or scale_factor != 2:
+            raise NotImplementedError("only prelu / dilation 1 / scale 2")
+        self.residual = nn.Sequential(
+            ConvP(in_channels, in_channels // 2, kernel, 1, kernel // 2, transposed=True),
+            BatchNormP(in_channels // 2), PReLUP(),
+            ConvP(in_channels // 2, out_channels, kernel, 2, kernel // 2, transposed=True))
+        self.skip = nn.Sequential(Marker("Upsample(scale_factor=2, mode=linear)"),
+                                  ConvP(in_channels, out_channels, kernel + 1, 1, kernel // 2))
+        self.add = nn.Sequential(BatchNormP(out_channels), PReLUP())
+
+
+def _flat_index(C, L):
+    """library feature l*Cp+c  ->  reference flatten index c*L+l (-1 on padded channels)."""
+    Cp = pad16(C)
+    idx = torch.full((L * Cp,), -1, dtype=torch.long)
+    for l in range(L):
+        idx[l * Cp: l * Cp + C] = torch.arange(C) * L + l
+    return idx
+
+
+class ResidualEncoder(nn.Module):
+    """residual.py:183-240."""
+
+    def __init__(self, in_channels, ch, kernel, z_dim, window, activation="prelu", is_diag=False, prior="gaussian",
+                 init_dilation=None):
+        super().__init__()
+        if prior != "gaussian":
+            raise NotImplementedError("prior='beta' is not on the BASELINE path")
+        if init_dilation is not None:
+            raise NotImplementedError("init_dilation is not supported by the HIP trunk yet")
+        self.conv_in = ConvP(in_channels, ch[0], 7, 1, 3)
+        self.activation = PReLUP()
+        self.res_layers = nn.Sequential(*[ResidualBlock(ch[i], ch[i + 1], kernel, activation) for i in range(len(ch) - 1)])
+        self.latent_len = find_latent_dim(window, kernel, len(ch) - 1)
+        flatten_dim = self.latent_len * ch[-1]
+        sig_dim = z_dim if is_diag else z_dim * (z_dim + 1) // 2
+        idx = _flat_index(ch[-1], self.latent_len)
+        self.fc_mu = LinearP(flatten_dim, z_dim, in_index=idx)
+        self.fc_sigma = nn.Sequential(LinearP(flatten_dim, sig_dim, in_index=idx), Marker("CholeskyL"))
+
+
+class ResidualDecoder(nn.Module):
+    """residual.py:243-292."""
+
+    def __init__(self, out_channels, ch, kernel, z_dim, window, activation="prelu", conditional_dim=0, init_dilation=None):
+        super().__init__()
+        self.conditional_dim = conditional_dim
+        n = len(ch) - 1
+        self.latent_len = find_latent_dim(window, kernel, n)
+        flatten_dim = self.latent_len * ch[-1]
+        self.fc_in = LinearP(z_dim + conditional_dim, flatten_dim, out_index=_flat_index(ch[-1], self.latent_len))
+        self.res_layers = nn.Sequential(*[ResidualBlockTranspose(ch[-i], ch[-i - 1], kernel, activation=activation)
+                                          for i in range(1, len(ch))])
+        l_out = find_out_dim(self.latent_len, kernel, n)
+        self.final_kernel = window - l_out + 7
+        self.conv_out = ConvP(ch[0], out_channels, self.final_kernel, 1, 3, transposed=True)
+
+
+class _TotalLoss(torch.autograd.Function):
+    """``batch_loss["total"]``: its backward runs the HIP reverse schedule and fills the
+    parameters' ``.grad`` (reference: ``batch_loss["total"].backward()``, trainer.py:163)."""
+
+    @staticmethod
+    def forward(ctx, anchor, total, model):
+        ctx.model = model
+        return total.detach().clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model.backward_from_seeds()
+        return None, None, None
+
+
+class ResVAE(nn.Module):
+    """Drop-in for scrubvae.model.residual.ResVAE (residual.py:365-491) on MI355X."""
+
+    def __init__(self, in_channels, ch=[64, 128, 256, 512, 1024], kernel=5, z_dim=128, window=200, activation="prelu",
+                 is_diag=False, conditional_dim=0, init_dilation=None, disentangle=None, kinematic_tree=None,
+                 arena_size=None, disentangle_keys=None, conditional_keys=None, discrete_classes=None,
+                 prior="gaussian", device="cuda"):
+        super().__init__()
+        self.prior = prior
+        self.dist_params = ["mu", "L"]
+        self.in_channels, self.ch, self.window = in_channels, list(ch), window
+        self.kernel, self.z_dim = kernel, z_dim
+        self.is_diag = is_diag
+        self.conditional_dim = conditional_dim
+        self.kinematic_tree = kinematic_tree
+        self.register_buffer("arena_size", None if arena_size is None else torch.as_tensor(arena_size, dtype=torch.float32))
+        self.disentangle_keys = disentangle_keys
+        self.conditional_keys = conditional_keys
+        self.discrete_classes = discrete_classes
+        self.n_keypts = (in_channels - (3 if arena_size is not None else 0)) // 6
+        if not is_diag:
+            raise NotImplementedError("full-Cholesky latent (model.diag=False) is not implemented on the HIP path yet")
+        self.encoder = ResidualEncoder(in_channels, ch, kernel, z_dim, window, activation, is_diag, prior, init_dilation)
+        self.decoder = ResidualDecoder(in_channels, ch, kernel, z_dim, window, activation, conditional_dim, init_dilation)
+        if self.encoder.latent_len < 1:
+            raise ValueError("window too short for the number of residual blocks")
+        self.disentangle = nn.ModuleDict()
+        if disentangle is not None:
+            for k, v in disentangle.items():
+                self.disentangle[k] = nn.ModuleDict(v)
+        self.mi_estimator = None
+        # engine state
+        self.world_size, self.rank, self.process_group = 1, 0, None
+        self.sync_bn = True
+        self._ws = {}
+        self._convs = {}
+        self._runners = {}
+        self._pending = None
+        self._tree = make_tree(self.n_keypts, kinematic_tree) if kinematic_tree is not None else None
+        self._arena_host = None if arena_size is None else [float(v) for v in torch.as_tensor(arena_size).flatten()]
+        self._materialise(torch.device(device))
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ parameters
+    def _materialise(self, device):
+        leaves = [(n, m) for n, m in self.named_modules() if isinstance(m, Leaf)]
+        total = 0
+        slots = []
+        for n, m in leaves:
+            for pname, shape in m.specs.items():
+                numel = 1
+                for s in shape:
+                    numel *= s
+                slots.append((m, pname, shape, total, numel))
+                total += (numel + 3) // 4 * 4
+        self.flat_params = torch.zeros(total, device=device)
+        self.flat_grads = torch.zeros(total, device=device)
+        self._slots = []
+        frozen = set()
+        for n, m in self.named_modules():
+            if isinstance(m, AdvNetScrubber):
+                frozen.update(id(x) for x in m.modules())
+        for m, pname, shape, off, numel in slots:
+            p = nn.Parameter(self.flat_params[off: off + numel].view(shape), requires_grad=id(m) not in frozen)
+            m.register_parameter(pname, p)
+            self._slots.append((p, off, numel, shape))
+        self.to(device)  # buffers
+        self._assign_grad_views()
+
+    def _assign_grad_views(self):
+        """Make every trainable parameter's .grad a view of the flat gradient buffer (the
+        reference loop sets param.grad = None before backward, trainer.py:160-161)."""
+        base = self.flat_grads.data_ptr()
+        for p, off, numel, shape in self._slots:
+            if not p.requires_grad:
+                continue
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                p.grad = self.flat_grads[off: off + numel].view(shape)
+
+    def _apply(self, fn, recurse=True):
+        # parameters are views of flat_params: moving/casting them individually would break
+        # the aliasing, so only buffers follow .to()/.cuda(); the flat storage is fixed at
+        # construction (device=...).
+        for m in self.modules():
+            for k, b in m._buffers.items():
+                if b is not None:
+                    m._buffers[k] = fn(b)
+        return self
+
+    def reset_parameters(self):
+        for m in self.modules():
+            if isinstance(m, Leaf):
+                m.reset_parameters()
+
+    def grads_state_dict(self):
+        """Gradients under the reference's parameter names and layouts (for parity checks)."""
+        out = {}
+        for name, m in self.named_modules():
+            if isinstance(m, Leaf):
+                for pn, p in m._parameters.items():
+                    if p is not None and p.grad is not None:
+                        out[f"{name}.{pn}"] = m.export_tensor(pn, p.grad)
+        return out
+
+    @property
+    def device(self):
+        return self.flat_params.device
+
+    # ------------------------------------------------------------------ workspace helpers
+    def _buf(self, name, shape, zero=False):
+        key = (name, tuple(shape))
+        t = self._ws.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=torch.float32)
+            self._ws[key] = t
+        return t
+
+    def _conv(self, name, p: ConvP, batch, l_in, ld_in=None, ld_out=None):
+        key = (name, batch, l_in, ld_in, ld_out)
+        c = self._convs.get(key)
+        if c is None:
+            c = ops.Conv(batch, l_in, p.c_in, p.c_out, p.kernel, p.stride, p.padding, p.dilation, p.transposed, ld_in, ld_out)
+            self._convs[key] = c
+        return c
+
+    def _lin(self, name, p: LinearP, batch, ld_in=None, ld_out=None):
+        key = (name, batch, ld_in, ld_out)
+        c = self._convs.get(key)
+        if c is None:
+            c = ops.Conv(batch, 1, p.in_lib, p.out_lib, 1, ld_in=ld_in, ld_out=ld_out)
+            self._convs[key] = c
+        return c
+
+    def _wgrad_ws(self, conv):
+        n = conv.wgrad_workspace_bytes() // 4 + 16
+        t = self._ws.get("wgrad_ws")
+        if t is None or t.numel() < n:
+            t = torch.empty(max(n, 1 << 20), device=self.device)
+            self._ws["wgrad_ws"] = t
+        return t
+
+    def _allreduce(self, t):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.process_group)
+
+    # ------------------------------------------------------------------ BN + PReLU stage
+    def _bn_act(self, tag, x, bn: BatchNormP, act: PReLUP, rows, out):
+        Cp = pad16(bn.c)
+        scale, shift = self._buf(tag + ".scale", (Cp,)), self._buf(tag + ".shift", (Cp,))
+        if self.training:
+            nch = ops.bn_chunks(rows)
+            part = self._buf(f"bn.part.{nch}.{Cp}", (nch, 2, Cp))
+            sums = self._buf(tag + ".sums", (2, Cp))
+            mean, rstd = self._buf(tag + ".mean", (Cp,)), self._buf(tag + ".rstd", (Cp,))
+            ops.bn_stats_partial(x, rows, Cp, Cp, part)
+            ops.bn_reduce_partials(part, nch, Cp, sums)
+            count = rows
+            if self.world_size > 1 and self.sync_bn:
+                self._allreduce(sums)
+                count = rows * self.world_size
+            ops.bn_finalize(sums, count, Cp, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                            mean, rstd, scale, shift)
+            bn.num_batches_tracked.add_(1)
+        else:
+            ops.bn_eval_coeffs(Cp, bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, scale, shift)
+        ops.affine_prelu_fwd(x, scale, shift, act.weight, out, rows, Cp, Cp)
+        return out
+
+    def _bn_act_bwd(self, tag, dy, x, bn: BatchNormP, act: PReLUP, rows, dx, acc):
+        Cp = pad16(bn.c)
+        nch = ops.bn_chunks(rows)
+        part = self._buf(f"bn.part.{nch}.{Cp}", (nch, 2, Cp))
+        dap = self._buf(f"bn.dap.{nch}.{Cp}", (nch * ((Cp + 63) // 64),))
+        scale, shift = self._buf(tag + ".scale", (Cp,)), self._buf(tag + ".shift", (Cp,))
+        mean, rstd = self._buf(tag + ".mean", (Cp,)), self._buf(tag + ".rstd", (Cp,))
+        sums = self._buf(tag + ".dsums", (2, Cp))
+        ops.affine_prelu_bwd_partial(dy, x, scale, shift, mean, rstd, act.weight, rows, Cp, Cp, part, dap)
+        ops.bn_reduce_partials(part, nch, Cp, sums)
+        count = rows
+        if self.world_size > 1 and self.sync_bn:
+            # parameter grads come from the LOCAL sums (the gradient all-reduce sums them
+            # later); the input gradient needs the global ones
+            gl = self._buf(tag + ".dsums_g", (2, Cp))
+            gl.copy_(sums)
+            self._allreduce(gl)
+            ops.affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, bn.weight, act.weight, gl, rows * self.world_size,
+                                       dx, rows, Cp, Cp, None, None, act.weight.grad, dap, nch, acc)
+            if acc:
+                ops.axpy(1.0, sums[0], bn.bias.grad)
+                ops.axpy(1.0, sums[1], bn.weight.grad)
+            else:
+                bn.bias.grad.copy_(sums[0])
+                bn.weight.grad.copy_(sums[1])
+        else:
+            ops.affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, bn.weight, act.weight, sums, count, dx, rows, Cp, Cp,
+                                       bn.weight.grad, bn.bias.grad, act.weight.grad, dap, nch, acc)
+        return dx
+
+    # ------------------------------------------------------------------ forward pieces
+    def normalize_root(self, root):
+        a = self.arena_size
+        return 2 * (root - a[0]) / (a[1] - a[0]) - 1
+
+    def inv_normalize_root(self, norm_root):
+        a = self.arena_size
+        return 0.5 * (norm_root + 1) * (a[1] - a[0]) + a[0]
+
+    def _prep(self, t):
+        t = t.to(self.device)
+        if t.dtype != torch.float32:
+            t = t.float()
+        return t.contiguous()
+
+    def _encode_trunk(self, data):
+        x6d = self._prep(data["x6d"])
+        B, W = x6d.shape[0], x6d.shape[1]
+        if W != self.window:
+            raise ValueError(f"window {W} != model.window {self.window}")
+        root = self._prep(data["root"]) if self.arena_size is not None else None
+        enc = self.encoder
+        Cin_p = pad16(self.in_channels)
+        rows = B * W
+        x_in = self._buf("x_in", (rows, Cin_p))
+        ops.pack_input(x6d, root, self._arena_host, x_in, self.n_keypts)
+        ch = self.ch
+        c0 = self._buf("enc.c_in", (rows, pad16(ch[0])))
+        self._conv("enc.conv_in", enc.conv_in, B, W).fwd(x_in, enc.conv_in.weight, enc.conv_in.bias, c0)
+        a = self._buf("enc.a0", (rows, pad16(ch[0])))
+        ops.affine_prelu_fwd(c0, None, None, enc.activation.weight, a, rows, pad16(ch[0]), pad16(ch[0]))
+        L = W
+        for i, blk in enumerate(enc.res_layers):
+            t = f"enc.{i}"
+            conv0, bn1, act1, conv3 = blk.residual
+            cv0 = self._conv(t + ".c0", conv0, B, L)
+            Lo = cv0.l_out
+            r0 = self._buf(t + ".r0", (B * Lo, cv0.c_out_p))
+            cv0.fwd(a, conv0.weight, conv0.bias, r0)
+            r0a = self._buf(t + ".r0a", (B * Lo, cv0.c_out_p))
+            self._bn_act(t + ".bn1", r0, bn1, act1, B * Lo, r0a)
+            cv3 = self._conv(t + ".c3", conv3, B, Lo)
+            s = self._buf(t + ".s", (B * Lo, cv3.c_out_p))
+            cv3.fwd(r0a, conv3.weight, conv3.bias, s)
+            self._conv(t + ".sk", blk.skip, B, L).fwd(a, blk.skip.weight, blk.skip.bias, s, accumulate=True)
+            a2 = self._buf(t + ".a", (B * Lo, cv3.c_out_p))
+            self._bn_act(t + ".bn2", s, blk.add[0], blk.add[1], B * Lo, a2)
+            a, L = a2, Lo
+        if L != enc.latent_len:
+            raise ValueError(f"encoder output length {L} != find_latent_dim {enc.latent_len} (reference would fail too)")
+        # heads: h = [mu | raw]
+        zp = pad16(self.z_dim)
+        flat = a.view(B, L * pad16(ch[-1]))
+        h = self._buf("enc.h", (B, 2 * zp), zero=True)
+        self._lin("fc_mu", enc.fc_mu, B, ld_out=2 * zp).fwd(flat, enc.fc_mu.weight, enc.fc_mu.bias, h)
+        fs = enc.fc_sigma[0]
+        self._lin("fc_sigma", fs, B, ld_out=2 * zp).fwd(flat, fs.weight, fs.bias, h[:, zp:])
+        return B, flat, h
+
+    def _heads(self, B, h, eps):
+        zp = pad16(self.z_dim)
+        zcp = pad16(self.z_dim + self.conditional_dim)
+        mu = self._buf("mu", (B, zp), zero=True)
+        sigma = self._buf("sigma", (B, zp), zero=True)
+        zc = self._buf("dec.zc", (B, zcp), zero=True)
+        klp = self._buf("kl_part", (ops.heads_blocks(B, self.z_dim),))
+        ops.heads_diag_fwd(h, 2 * zp, eps, mu, sigma, zc, zcp, klp, B, self.z_dim, raw_off=zp, ldm=zp)
+        return mu, sigma, zc, klp
+
+    def _conditional_var(self, data, B):
+        parts = []
+        for k in self.conditional_keys:
+            v = data[k].to(self.device)
+            if self.discrete_classes is not None and k in self.discrete_classes.keys():
+                parts.append(F.one_hot(v.ravel().long(), len(self.discrete_classes[k])).float())
+            else:
+                parts.append(v.float())
+        return torch.cat(parts, dim=-1)
+
+    def _decode_trunk(self, B, zc):
+        dec = self.decoder
+        ch = self.ch
+        L = dec.latent_len
+        Ctop = pad16(ch[-1])
+        f = self._buf("dec.f", (B, L * Ctop))
+        self._lin("fc_in", dec.fc_in, B).fwd(zc, dec.fc_in.weight, dec.fc_in.bias, f)
+        d = f.view(B * L, Ctop)
+        for j, blk in enumerate(dec.res_layers):
+            t = f"dec.{j}"
+            ct1, bn1, act1, ct2 = blk.residual
+            cv1 = self._conv(t + ".t1", ct1, B, L)
+            t0 = self._buf(t + ".t0", (B * L, cv1.c_out_p))
+            cv1.fwd(d, ct1.weight, ct1.bias, t0)
+            t0a = self._buf(t + ".t0a", (B * L, cv1.c_out_p))
+            self._bn_act(t + ".bn1", t0, bn1, act1, B * L, t0a)
+            cv2 = self._conv(t + ".t2", ct2, B, L)
+            Lo = cv2.l_out
+            s = self._buf(t + ".s", (B * Lo, cv2.c_out_p))
+            cv2.fwd(t0a, ct2.weight, ct2.bias, s)
+            up = self._buf(t + ".up", (B * 2 * L, cv1.c_in_p))
+            ops.upsample2_fwd(d, up, B, L, cv1.c_in_p, cv1.c_in_p)
+            sk = blk.skip[1]
+            cvs = self._conv(t + ".sk", sk, B, 2 * L)
+            if cvs.l_out != Lo:
+                raise ValueError("skip / residual length mismatch")
+            cvs.fwd(up, sk.weight, sk.bias, s, accumulate=True)
+            d2 = self._buf(t + ".a", (B * Lo, cv2.c_out_p))
+            self._bn_act(t + ".bn2", s, blk.add[0], blk.add[1], B * Lo, d2)
+            d, L = d2, Lo
+        cvo = self._conv("dec.out", dec.conv_out, B, L)
+        if cvo.l_out != self.window:
+            raise ValueError(f"decoder output length {cvo.l_out} != window {self.window}")
+        y = self._buf("dec.y", (B * self.window, cvo.c_out_p))
+        cvo.fwd(d, dec.conv_out.weight, dec.conv_out.bias, y)
+        return y
+
+    def _run_tail(self, B, data, jpe_scale, root_scale, ext_dx6d, with_grad):
+        """Fused tanh/unpack/FK/loss tail.  Without offsets/target in `data` (pure forward)
+        zero stand-ins are used and the loss partials are ignored."""
+        rows = B * self.window
+        J = self.n_keypts
+        y = self._buf("dec.y", (rows, pad16(self.in_channels)))
+        x6d_hat = self._buf("out.x6d", (B, self.window, J, 6))
+        root_hat = self._buf("out.root", (B, self.window, 3)) if self.arena_size is not None else None
+        lp = self._buf("tail.part", (ops.tail_blocks(rows), 2))
+        offsets = self._prep(data["offsets"]) if "offsets" in data else self._buf("zero.j3", (rows, J, 3), zero=True)
+        target = self._prep(data["target_pose"]) if "target_pose" in data else self._buf("zero.j3", (rows, J, 3), zero=True)
+        root = self._prep(data["root"]) if self.arena_size is not None else None
+        dy = self._buf("dec.dy", (rows, pad16(self.in_channels))) if with_grad else None
+        ops.pose_tail(y, y.shape[1], offsets, target, root, self._arena_host, self._tree, jpe_scale, root_scale,
+                      ext_dx6d, None, x6d_hat, root_hat, lp, dy, rows, pre_tanh=True)
+        return x6d_hat, root_hat, lp, dy
+
+    # ------------------------------------------------------------------ reference API
+    def encode(self, data):
+        """ResVAE.encode (residual.py:438-459): returns {"mu": [B,z], "L": [B,z,z]}."""
+        B, flat, h = self._encode_trunk(data)
+        mu, sigma, zc, klp = self._heads(B, h, None)
+        self._state = dict(B=B, flat=flat, h=h, eps=None)
+        return {"mu": mu[:, : self.z_dim], "L": torch.diag_embed(sigma[:, : self.z_dim])}
+
+    def decode(self, z, data):
+        """ResVAE.decode (residual.py:461-491)."""
+        B = z.shape[0]
+        zcp = pad16(self.z_dim + self.conditional_dim)
+        zc = self._buf("dec.zc", (B, zcp), zero=True)
+        zc[:, : self.z_dim] = z.to(self.device)
+        data_o = {}
+        if self.conditional_dim > 0:
+            data_o["var"] = self._conditional_var(data, B)
+            zc[:, self.z_dim: self.z_dim + self.conditional_dim] = data_o["var"]
+        self._decode_trunk(B, zc)
+        x6d_hat, root_hat, _, _ = self._run_tail(B, data, 0.0, 0.0, None, False)
+        if root_hat is not None:
+            data_o["root"] = root_hat
+        data_o["x6d"] = x6d_hat
+        return data_o
+
+    def sampling_noise(self, B):
+        """eps ~ N(0, I) for the reparameterisation (residual.py:315).  Override or pass
+        data["eps"] to inject noise (parity tests)."""
+        return torch.randn(B, self.z_dim, device=self.device)
+
+    def forward(self, data):
+        """VAE.forward (residual.py:318-362).  Returns data_o with mu, L, z, x6d, root, var,
+        disentangle[method][feature]."""
+        B, flat, h = self._encode_trunk(data)
+        eps = None
+        if self.training:
+            eps = self._prep(data["eps"]) if "eps" in data else self.sampling_noise(B)
+        mu, sigma, zc, klp = self._heads(B, h, eps)
+        data_o = {"mu": mu[:, : self.z_dim], "L": torch.diag_embed(sigma[:, : self.z_dim])}
+        data_o["z"] = zc[:, : self.z_dim]
+        if self.conditional_dim > 0:
+            data_o["var"] = self._conditional_var(data, B)
+            zc[:, self.z_dim: self.z_dim + self.conditional_dim] = data_o["var"]
+        self._decode_trunk(B, zc)
+        x6d_hat, root_hat, _, _ = self._run_tail(B, data, 0.0, 0.0, None, False)
+        data_o["x6d"] = x6d_hat
+        if root_hat is not None:
+            data_o["root"] = root_hat
+        # scrubber heads (all take mu, residual.py:337-360)
+        data_o["disentangle"] = {}
+        for method, module_dict in self.disentangle.items():
+            data_o["disentangle"][method] = {}
+            for k, m in module_dict.items():
+                if method == "grad_reversal":
+                    outs = self._runner(method, k, m.ensemble, B).forward(mu)
+                    data_o["disentangle"][method][k] = [o[:, : m.ensemble.out_dim] for o in outs]
+                elif method == "adversarial_net":
+                    x = self._buf(f"an.{k}.x0", (B, pad16(m.ensemble.in_dim)), zero=True)
+                    x[:, : self.z_dim] = mu[:, : self.z_dim]
+                    x[:, self.z_dim: self.z_dim + self.conditional_dim] = data_o["var"]
+                    outs = self._runner(method + ".fwd", k, m.ensemble, B).forward(x)
+                    data_o["disentangle"][method][k] = [torch.softmax(o[:, :2], -1) for o in outs]
+                else:
+                    raise NotImplementedError(f"scrubber '{method}' is outside this build's scope (SURVEY 8a row A2)")
+        self._state = dict(B=B, flat=flat, h=h, eps=eps, mu=mu, sigma=sigma, zc=zc, klp=klp, data=data)
+        return data_o
+
+    def _runner(self, method, key, ens: MLPEnsemble, rows):
+        k = (method, key, rows)
+        r = self._runners.get(k)
+        if r is None:
+            r = EnsembleRunner(ens, rows, self.device)
+            self._runners[k] = r
+        return r
+
+    # ------------------------------------------------------------------ backward schedule
+    def make_total(self, total):
+        """Wrap the device scalar `total` so that ``total.backward()`` runs the HIP backward."""
+        anchor = self.flat_params.new_zeros((), requires_grad=True)
+        return _TotalLoss.apply(anchor, total, self)
+
+    def backward_from_seeds(self):
+        """Reverse schedule.  Needs the seeds prepared by train.losses.get_batch_loss:
+        pending = {dy [rows,Cp], kl_scale, d_mu [B,zp] or None, scrub: [...]}"""
+        pend = self._pending
+        if pend is None:
+            raise RuntimeError("backward called without a preceding get_batch_loss on this model")
+        st = self._state
+        B = st["B"]
+        self._assign_grad_views()
+        acc = pend.get("accumulate", False)
+        enc, dec, ch = self.encoder, self.decoder, self.ch
+        zp = pad16(self.z_dim)
+        d_mu = pend["d_mu"]  # [B, zp] zero-initialised seed for scrubber grads
+        # ---- scrubber heads: MLP backward, seeds into d_mu
+        for item in pend["scrub"]:
+            runner, d_outs, kind = item["runner"], item["d_outs"], item["kind"]
+            g_in = runner.backward(d_outs, param_grads=(kind == "gr"), accumulate=acc)
+            if kind == "gr":
+                ops.axpy(-item["alpha"], g_in, d_mu)  # gradient reversal: -alpha * grad
+            else:  # adversarial net on cat([mu;mu],[v;v_shuffle]): both halves feed mu
+                tmp = self._buf("an.gmu", (B, zp), zero=True)
+                tmp[:, : self.z_dim] = g_in[:B, : self.z_dim] + g_in[B:, : self.z_dim]
+                ops.axpy(1.0, tmp, d_mu)
+        # ---- decoder
+        W = self.window
+        rows = B * W
+        dy = pend["dy"]
+        lens = [dec.latent_len]
+        for _ in dec.res_layers:
+            lens.append((lens[-1] - 1) * 2 - 2 * (self.kernel // 2) + (self.kernel - 1) + 1)
+        d_in_last = self._buf(f"dec.{len(dec.res_layers) - 1}.a", (B * lens[-1], pad16(ch[0])))
+        cvo = self._conv("dec.out", dec.conv_out, B, lens[-1])
+        cvo.wgrad(d_in_last, dy, dec.conv_out.weight.grad, dec.conv_out.bias.grad, self._wgrad_ws(cvo), accumulate=acc)
+        g = self._buf("g.dec.top", (B * lens[-1], pad16(ch[0])))
+        cvo.dgrad(dy, dec.conv_out.weight, g)
+        for j in range(len(dec.res_layers) - 1, -1, -1):
+            blk = dec.res_layers[j]
+            t = f"dec.{j}"
+            L, Lo = lens[j], lens[j + 1]
+            ct1, bn1, act1, ct2 = blk.residual
+            sk = blk.skip[1]
+            cv1 = self._conv(t + ".t1", ct1, B, L)
+            cv2 = self._conv(t + ".t2", ct2, B, L)
+            cvs = self._conv(t + ".sk", sk, B, 2 * L)
+            d_in = self._buf(f"dec.{j - 1}.a", (B * L, cv1.c_in_p)) if j > 0 else self._buf("dec.f", (B, L * cv1.c_in_p)).view(B * L, cv1.c_in_p)
+            s = self._buf(t + ".s", (B * Lo, cv2.c_out_p))
+            g_s = self._buf("g." + t + ".s", (B * Lo, cv2.c_out_p))
+            self._bn_act_bwd(t + ".bn2", g, s, blk.add[0], blk.add[1], B * Lo, g_s, acc)
+            up = self._buf(t + ".up", (B * 2 * L, cv1.c_in_p))
+            t0a = self._buf(t + ".t0a", (B * L, cv1.c_out_p))
+            cvs.wgrad(up, g_s, sk.weight.grad, sk.bias.grad, self._wgrad_ws(cvs), accumulate=acc)
+            cv2.wgrad(t0a, g_s, ct2.weight.grad, ct2.bias.grad, self._wgrad_ws(cv2), accumulate=acc)
+            g_up = self._buf("g." + t + ".up", (B * 2 * L, cv1.c_in_p))
+            cvs.dgrad(g_s, sk.weight, g_up)
+            g_d = self._buf("g." + t + ".in", (B * L, cv1.c_in_p))
+            ops.upsample2_bwd(g_up, g_d, B, L, cv1.c_in_p, cv1.c_in_p)
+            g_t0a = self._buf("g." + t + ".t0a", (B * L, cv1.c_out_p))
+            cv2.dgrad(g_s, ct2.weight, g_t0a)
+            t0 = self._buf(t + ".t0", (B * L, cv1.c_out_p))
+            g_t0 = self._buf("g." + t + ".t0", (B * L, cv1.c_out_p))
+            self._bn_act_bwd(t + ".bn1", g_t0a, t0, bn1, act1, B * L, g_t0, acc)
+            cv1.wgrad(d_in, g_t0, ct1.weight.grad, ct1.bias.grad, self._wgrad_ws(cv1), accumulate=acc)
+            cv1.dgrad(g_t0, ct1.weight, g_d, accumulate=True)
+            g = g_d
+        # ---- fc_in
+        zc = st["zc"]
+        zcp = zc.shape[1]
+        lin = self._lin("fc_in", dec.fc_in, B)
+        g_f = g.view(B, -1)
+        lin.wgrad(zc, g_f, dec.fc_in.weight.grad, dec.fc_in.bias.grad, self._wgrad_ws(lin), accumulate=acc)
+        g_zc = self._buf("g.zc", (B, zcp))
+        lin.dgrad(g_f, dec.fc_in.weight, g_zc)
+        # ---- heads: dh = [dmu | draw]
+        h = st["h"]
+        dh = self._buf("g.h", (B, 2 * zp), zero=True)
+        ops.heads_diag_bwd(h, 2 * zp, st["eps"], st["sigma"], g_zc, zcp, d_mu, None, pend["kl_scale"], dh, B, self.z_dim,
+                           raw_off=zp, ldm=zp)
+        flat = st["flat"]
+        fm, fs = enc.fc_mu, enc.fc_sigma[0]
+        lm = self._lin("fc_mu", fm, B, ld_out=2 * zp)
+        ls = self._lin("fc_sigma", fs, B, ld_out=2 * zp)
+        lm.wgrad(flat, dh, fm.weight.grad, fm.bias.grad, self._wgrad_ws(lm), accumulate=acc)
+        ls.wgrad(flat, dh[:, zp:], fs.weight.grad, fs.bias.grad, self._wgrad_ws(ls), accumulate=acc)
+        g_flat = self._buf("g.flat", tuple(flat.shape))
+        lm.dgrad(dh, fm.weight, g_flat)
+        ls.dgrad(dh[:, zp:], fs.weight, g_flat, accumulate=True)
+        # ---- encoder blocks
+        elens = [W]
+        for blk in enc.res_layers:
+            elens.append((elens[-1] + 2 * (self.kernel // 2) - (self.kernel - 1) - 1) // 2 + 1)
+        g = g_flat.view(B * elens[-1], pad16(ch[-1]))
+        for i in range(len(enc.res_layers) - 1, -1, -1):
+            blk = enc.res_layers[i]
+            t = f"enc.{i}"
+            L, Lo = elens[i], elens[i + 1]
+            conv0, bn1, act1, conv3 = blk.residual
+            cv0 = self._conv(t + ".c0", conv0, B, L)
+            cv3 = self._conv(t + ".c3", conv3, B, Lo)
+            cvs = self._conv(t + ".sk", blk.skip, B, L)
+            a_in = self._buf(f"enc.{i - 1}.a", (B * L, cv0.c_in_p)) if i > 0 else self._buf("enc.a0", (B * L, cv0.c_in_p))
+            s = self._buf(t + ".s", (B * Lo, cv3.c_out_p))
+            g_s = self._buf("g." + t + ".s", (B * Lo, cv3.c_out_p))
+            self._bn_act_bwd(t + ".bn2", g, s, blk.add[0], blk.add[1], B * Lo, g_s, acc)
+            r0a = self._buf(t + ".r0a", (B * Lo, cv0.c_out_p))
+            cvs.wgrad(a_in, g_s, blk.skip.weight.grad, blk.skip.bias.grad, self._wgrad_ws(cvs), accumulate=acc)
+            cv3.wgrad(r0a, g_s, conv3.weight.grad, conv3.bias.grad, self._wgrad_ws(cv3), accumulate=acc)
+            g_r0a = self._buf("g." + t + ".r0a", (B * Lo, cv0.c_out_p))
+            cv3.dgrad(g_s, conv3.weight, g_r0a)
+            r0 = self._buf(t + ".r0", (B * Lo, cv0.c_out_p))
+            g_r0 = self._buf("g." + t + ".r0", (B * Lo, cv0.c_out_p))
+            self._bn_act_bwd(t + ".bn1", g_r0a, r0, bn1, act1, B * Lo, g_r0, acc)
+            cv0.wgrad(a_in, g_r0, conv0.weight.grad, conv0.bias.grad, self._wgrad_ws(cv0), accumulate=acc)
+            g_a = self._buf("g." + t + ".in", (B * L, cv0.c_in_p))
+            cvs.dgrad(g_s, blk.skip.weight, g_a)
+            cv0.dgrad(g_r0, conv0.weight, g_a, accumulate=True)
+            g = g_a
+        # ---- conv_in (bare PReLU in front)
+        C0 = pad16(ch[0])
+        c0 = self._buf("enc.c_in", (rows, C0))
+        nch = ops.bn_chunks(rows)
+        part = self._buf(f"bn.part.{nch}.{C0}", (nch, 2, C0))
+        dap = self._buf(f"bn.dap.{nch}.{C0}", (nch * ((C0 + 63) // 64),))
+        ops.affine_prelu_bwd_partial(g, c0, None, None, None, None, enc.activation.weight, rows, C0, C0, part, dap)
+        g_c0 = self._buf("g.enc.c_in", (rows, C0))
+        ops.affine_prelu_bwd_apply(g, c0, None, None, None, None, None, enc.activation.weight, None, 1.0, g_c0, rows, C0, C0,
+                                   None, None, enc.activation.weight.grad, dap, nch, acc)
+        x_in = self._buf("x_in", (rows, pad16(self.in_channels)))
+        cvi = self._conv("enc.conv_in", enc.conv_in, B, W)
+        cvi.wgrad(x_in, g_c0, enc.conv_in.weight.grad, enc.conv_in.bias.grad, self._wgrad_ws(cvi), accumulate=acc)
+        # ---- data-parallel: sum gradients over ranks (losses are normalised by the GLOBAL batch)
+        if self.world_size > 1:
+            self._allreduce(self.flat_grads)
+        self._pending = None

@@ -179,13 +179,14 @@ def heads_blocks(batch, z):
     return int(_lib.lib().svae_heads_blocks(batch, z))
 
 
-def heads_diag_fwd(h, ld, eps, mu, sigma, z, ldz, kl_part, batch, zdim):
-    check(_lib.lib().svae_heads_diag_fwd(_p(h), ld, _p(eps), _p(mu), _p(sigma), _p(z), ldz, _p(kl_part), batch, zdim, _stream()), "heads_diag_fwd")
+def heads_diag_fwd(h, ld, eps, mu, sigma, z, ldz, kl_part, batch, zdim, raw_off=None, ldm=None):
+    check(_lib.lib().svae_heads_diag_fwd(_p(h), ld, _p(eps), _p(mu), _p(sigma), _p(z), ldz, _p(kl_part), batch, zdim,
+                                         zdim if raw_off is None else raw_off, ldm or zdim, _stream()), "heads_diag_fwd")
 
 
-def heads_diag_bwd(h, ld, eps, sigma, dz, lddz, dmu, dsigma, kl_scale, dh, batch, zdim):
+def heads_diag_bwd(h, ld, eps, sigma, dz, lddz, dmu, dsigma, kl_scale, dh, batch, zdim, raw_off=None, ldm=None):
     check(_lib.lib().svae_heads_diag_bwd(_p(h), ld, _p(eps), _p(sigma), _p(dz), lddz, _p(dmu), _p(dsigma), float(kl_scale), _p(dh),
-                                         batch, zdim, _stream()), "heads_diag_bwd")
+                                         batch, zdim, zdim if raw_off is None else raw_off, ldm or zdim, _stream()), "heads_diag_bwd")
 
 
 def tail_blocks(rows):
@@ -193,10 +194,10 @@ def tail_blocks(rows):
 
 
 def pose_tail(y, ld, offsets, target, root, arena_host, tree, jpe_scale, root_scale, ext_dx6d, ext_droot,
-              x6d_hat, root_hat, loss_part, dy, rows):
+              x6d_hat, root_hat, loss_part, dy, rows, pre_tanh=True):
     check(_lib.lib().svae_pose_tail(_p(y), ld, _p(offsets), _p(target), _p(root), _arena_ptr(arena_host), C.byref(tree),
                                     float(jpe_scale), float(root_scale), _p(ext_dx6d), _p(ext_droot), _p(x6d_hat), _p(root_hat),
-                                    _p(loss_part), _p(dy), rows, _stream()), "pose_tail")
+                                    _p(loss_part), _p(dy), rows, int(pre_tanh), _stream()), "pose_tail")
 
 
 def rot_blocks(n):

@@ -1,0 +1,2 @@
+from . import losses
+from .trainer import *  # noqa: F401,F403

@@ -1,0 +1,179 @@
+"""get_batch_loss for the MI355X ResVAE (reference: src/scrubvae/train/losses.py:182-324).
+
+Same signature and dict contract as the reference:
+
+    batch_loss = get_batch_loss(model, data, data_o, loss_scale, disentangle_config)
+    batch_loss["total"].backward()
+
+Every term is computed by HIP kernels; each kernel that evaluates a loss also writes the
+seed gradient of ``loss_scale[k] * loss_k`` with respect to the network output it reads
+(fused forward+backward of the loss), and ``total.backward()`` then runs the model's
+reverse schedule from those seeds.  Dispatch is by key presence in ``loss_scale`` exactly
+as in the reference (losses.py:186-219,311), including its quirks: JPE uses root_hat=None
+(:209-214), the rotation loss is not divided by the batch (:136), the gradient-reversal
+ensemble is normalised inside the loop (:279-284), the adversarial net applies
+CrossEntropyLoss to its own softmax output (:304-307).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from ..ops import pad16
+
+SUPPORTED = ("rotation", "prior", "jpe", "root")
+
+
+def _scalar(model, name):
+    return model._buf("loss." + name, (1,), zero=True)
+
+
+def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm=None):
+    """adv_perm: optional dict feature -> LongTensor permutation replacing torch.randperm in
+    AdvNetScrubber.shuffle (disentangle.py:680) -- for parity tests."""
+    st = getattr(model, "_state", None)
+    if st is None or "klp" not in st:
+        raise RuntimeError("get_batch_loss needs the data_o of the immediately preceding model(data) call")
+    B = st["B"]
+    W, J, z = model.window, model.n_keypts, model.z_dim
+    zp = pad16(z)
+    world = model.world_size
+    Bg = B * world  # losses are normalised by the GLOBAL batch so that summed grads match 1 GPU
+    train = model.training and torch.is_grad_enabled()
+    for k in loss_scale.keys():
+        if k in SUPPORTED or k.endswith("_gr") or k.endswith("_an"):
+            continue
+        raise NotImplementedError(f"loss '{k}' is outside this build's scope (SURVEY 8a: L5/A2 rows)")
+    batch_loss = {}
+    total = _scalar(model, "total")
+    total.zero_()
+    dev_data = {k: v for k, v in data.items()}
+
+    def add_total(key, value):
+        if loss_scale[key] != 0:
+            ops.axpy(float(loss_scale[key]), value, total)
+
+    # ---- rotation (L4): seeds an extra gradient on x6d_hat that the tail adds
+    ext_dx6d = None
+    if "rotation" in loss_scale:
+        n = B * W * J
+        part = model._buf("rot.part", (ops.rot_blocks(n),))
+        x6d = model._prep(data["x6d"])
+        x6d_hat = model._buf("out.x6d", (B, W, J, 6))
+        ext_dx6d = model._buf("rot.dx", (B * W, J * 6)) if train else None
+        ops.rot_loss(x6d, x6d_hat, float(loss_scale["rotation"]), part, ext_dx6d, n)
+        v = _scalar(model, "rotation")
+        ops.reduce_rows(part, part.numel(), 1, 1.0, v)
+        batch_loss["rotation"] = v.view(()).clone()
+        add_total("rotation", v)
+
+    # ---- prior (L3): KL partials were produced by the heads kernel in forward
+    kl_scale = 0.0
+    if "prior" in loss_scale:
+        v = _scalar(model, "prior")
+        ops.reduce_rows(st["klp"], st["klp"].numel(), 1, 1.0 / Bg, v)
+        batch_loss["prior"] = v.view(()).clone()
+        add_total("prior", v)
+        kl_scale = float(loss_scale["prior"]) / Bg
+
+    # ---- jpe (L1) + root (L2): fused tail, also produces d total / d conv_out
+    jpe_s = float(loss_scale.get("jpe", 0.0)) / (Bg * 3 * J)
+    root_s = float(loss_scale.get("root", 0.0)) / Bg
+    if "jpe" in loss_scale and ("offsets" not in data or "target_pose" not in data):
+        raise KeyError("jpe loss needs data['offsets'] and data['target_pose']")
+    _, _, lp, dy = model._run_tail(B, dev_data, jpe_s, root_s, ext_dx6d, train)
+    nb = lp.shape[0]
+    if "jpe" in loss_scale:
+        v = _scalar(model, "jpe")
+        ops.reduce_rows(lp, nb, 2, 1.0 / (Bg * 3 * J), model._buf("tail.sums", (2,)))
+        v.copy_(model._buf("tail.sums", (2,))[0:1])
+        batch_loss["jpe"] = v.view(()).clone()
+        add_total("jpe", v)
+    if "root" in loss_scale:
+        v = _scalar(model, "root")
+        ops.reduce_rows(lp, nb, 2, 1.0 / Bg, model._buf("tail.sums2", (2,)))
+        v.copy_(model._buf("tail.sums2", (2,))[1:2])
+        batch_loss["root"] = v.view(()).clone()
+        add_total("root", v)
+
+    # ---- scrubbing losses
+    d_mu = model._buf("seed.d_mu", (B, zp), zero=True)
+    if train:
+        d_mu.zero_()
+    scrub = []
+    methods = disentangle_config["method"] if disentangle_config is not None else {}
+    for method, keys in methods.items():
+        nk = len(keys)
+        for key in keys:
+            if method == "conditional":
+                continue
+            if method == "grad_reversal":
+                m = model.disentangle[method][key]
+                runner = model._runner(method, key, m.ensemble, B)
+                outs = [l[-1]["pre"] for l in runner.members]
+                out_dim, out_p = m.ensemble.out_dim, pad16(m.ensemble.out_dim)
+                c = 4.0 * nk * Bg
+                weights = [c ** -4, c ** -3, c ** -2, c ** -1]  # normalisation inside the loop (losses.py:279-284)
+                lk = key + "_gr"
+                v = _scalar(model, lk)
+                v.zero_()
+                d_outs = []
+                nb_r = ops.rowloss_blocks(B)
+                for i, (o, w) in enumerate(zip(outs, weights)):
+                    part = model._buf(f"gr.part.{i}", (nb_r,))
+                    dpred = model._buf(f"gr.{key}.d{i}", (B, out_p), zero=True) if train else None
+                    sc = float(loss_scale[lk]) * w
+                    if key == "ids":
+                        labels = data[key].to(model.device).ravel().int().contiguous()
+                        ops.ce_sum(o, out_p, labels, B, out_dim, sc, part, dpred)
+                    else:
+                        tgt = model._prep(data[key])
+                        ops.mse_sum(o, out_p, tgt, tgt.shape[-1], B, out_dim, sc, part, dpred)
+                    ops.reduce_rows(part, nb_r, 1, w, v, accumulate=True)
+                    d_outs.append(dpred)
+                batch_loss[lk] = v.view(()).clone()
+                add_total(lk, v)
+                if train and loss_scale[lk] != 0:
+                    scrub.append(dict(kind="gr", runner=runner, d_outs=d_outs, alpha=m.alpha))
+            elif method == "adversarial_net":
+                m = model.disentangle[method][key]
+                v_ind = model.disentangle_keys.index(key)
+                var = data_o["var"]
+                perm = adv_perm[key].to(model.device) if adv_perm is not None else torch.randperm(B, device=model.device)
+                in_p = pad16(m.ensemble.in_dim)
+                x = model._buf(f"an.{key}.x", (2 * B, in_p), zero=True)
+                mu = st["mu"]
+                x[:B, :z] = mu[:, :z]
+                x[B:, :z] = mu[:, :z]
+                D = model.conditional_dim
+                x[:B, z: z + D] = var
+                x[B:, z: z + D] = var
+                x[B:, z + v_ind] = var[perm, v_ind]  # one COLUMN of var is shuffled (disentangle.py:680)
+                runner = model._runner(method, key, m.ensemble, 2 * B)
+                outs = runner.forward(x)
+                lk = key + "_an"
+                vv = _scalar(model, lk)
+                vv.zero_()
+                nb_r = ops.rowloss_blocks(2 * B)
+                w = -1.0 / (4 * Bg)
+                d_outs = []
+                for i, o in enumerate(outs):
+                    part = model._buf(f"an.part.{i}", (nb_r,))
+                    dl = model._buf(f"an.{key}.d{i}", (2 * B, 16), zero=True) if train else None
+                    ops.double_softmax_ce_sum(o, 16, 2 * B, float(loss_scale[lk]) * w, part, dl)
+                    ops.reduce_rows(part, nb_r, 1, w, vv, accumulate=True)
+                    d_outs.append(dl)
+                batch_loss[lk] = vv.view(()).clone()
+                add_total(lk, vv)
+                if train and loss_scale[lk] != 0:
+                    scrub.append(dict(kind="an", runner=runner, d_outs=d_outs))
+            else:
+                raise NotImplementedError(f"scrubber '{method}' is outside this build's scope (SURVEY 8a row A2)")
+
+    if train:
+        model._pending = dict(dy=dy, kl_scale=kl_scale, d_mu=d_mu, scrub=scrub,
+                              accumulate=getattr(model, "accumulate_grads", False))
+        batch_loss["total"] = model.make_total(total.view(()))
+    else:
+        batch_loss["total"] = total.view(()).clone()
+    return batch_loss

@@ -1,0 +1,210 @@
+"""Training loop drop-in (reference: src/scrubvae/train/trainer.py:26-212,322-516).
+
+``train_test_epoch`` keeps the reference's signature and per-batch order of operations
+(forward, losses, grad=None, backward, clip_grad_norm_(1e6), optimizer step, scheduler step
+with fractional epoch, device-side metric accumulation, one host read per epoch).  The
+optimizer returned by ``get_optimizer_and_lr_scheduler`` is a fused single-launch
+Adam/AdamW over the model's flat parameter buffer (``FusedAdam``); any torch.optim
+optimizer built on ``model.parameters()`` works too.
+"""
+from __future__ import annotations
+
+import math
+import time
+from pathlib import Path
+
+import torch
+
+from .. import ops
+from .losses import get_batch_loss
+
+__all__ = ["CyclicalBetaAnnealing", "get_beta_schedule", "get_optimizer_and_lr_scheduler", "predict_batch",
+           "train_test_epoch", "train_epoch", "train", "FusedAdam", "clip_grad_norm_"]
+
+
+class CyclicalBetaAnnealing:
+    """trainer.py:26-40."""
+
+    def __init__(self, beta_max=1, len_cycle=100, R=0.5):
+        self.beta_max, self.len_cycle, self.R = beta_max, len_cycle, R
+        self.len_increasing = int(len_cycle * R)
+
+    def get(self, epoch):
+        remainder = (epoch - 1) % self.len_cycle
+        if remainder >= self.len_increasing:
+            return self.beta_max
+        return self.beta_max * remainder / self.len_increasing
+
+
+def get_beta_schedule(schedule, beta):
+    """trainer.py:43-51 (note: the reference passes loss.prior as `schedule`, :336-339)."""
+    if schedule == "cyclical":
+        print("Initializing cyclical beta annealing")
+        return CyclicalBetaAnnealing(beta_max=beta)
+    print("No beta annealing selected")
+    return None
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam / AdamW semantics (defaults: betas (0.9,0.999), eps 1e-8, weight decay
+    0 / 0.01; trainer.py:60-65) as ONE HIP launch over the model's flat parameter, gradient
+    and moment buffers.  ``param_groups[0]["lr"]`` is honoured, so torch LR schedulers work."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
+        self.model = model
+        params = [p for p in model.parameters() if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled))
+        self.exp_avg = torch.zeros_like(model.flat_params)
+        self.exp_avg_sq = torch.zeros_like(model.flat_params)
+        self.step_count = 0
+        self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self.step_count += 1
+        m = self.model
+        m._assign_grad_views()
+        ops.adam_step(m.flat_params, m.flat_grads, self.exp_avg, self.exp_avg_sq, float(g["lr"]), g["betas"][0],
+                      g["betas"][1], g["eps"], g["weight_decay"], self.step_count, g["decoupled"], self.grad_scale)
+
+    def zero_grad(self, set_to_none=True):
+        pass  # gradients are overwritten by every backward
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+
+
+def clip_grad_norm_(model, max_norm=1e6):
+    """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) on the flat gradient
+    buffer (trainer.py:164).  Returns the total norm as a device tensor.  With the
+    reference's max_norm=1e6 the clip never bites; if it does, the gradients are scaled."""
+    n = model.flat_grads.numel()
+    part = model._buf("gn.part", (ops.sumsq_blocks(n),))
+    out = model._buf("gn.out", (1,))
+    ops.sumsq_partial(model.flat_grads, part)
+    ops.reduce_rows(part, part.numel(), 1, 1.0, out)
+    norm = out.sqrt()
+    if max_norm < 1e5:  # only then can it matter in fp32 training; costs one tiny torch op
+        coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        model.flat_grads.mul_(coef)
+    return norm.view(())
+
+
+def get_optimizer_and_lr_scheduler(model, train_config, load_path=None, start_epoch=None):
+    """trainer.py:54-89."""
+    name = train_config["optimizer"]
+    if name == "adam":
+        print("Initializing Adam optimizer ...")
+        optimizer = FusedAdam(model, lr=train_config["lr"])
+    elif name == "adamw":
+        print("Initializing AdamW optimizer ...")
+        optimizer = FusedAdam(model, lr=train_config["lr"], weight_decay=0.01, decoupled=True)
+    elif name == "sgd":
+        print("Initializing SGD optimizer ...")
+        optimizer = torch.optim.SGD(model.parameters(), lr=train_config["lr"], momentum=0.2, nesterov=True)
+    else:
+        raise ValueError("No valid optimizer selected")
+    scheduler = None
+    if train_config.get("lr_schedule") == "cawr":
+        print("Initializing cosine annealing w/warm restarts learning rate scheduler")
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(optimizer, T_0=50)
+    else:
+        print("No learning rate scheduler selected")
+    if load_path is not None:
+        ck = Path("{}/checkpoints/epoch_{}.pth".format(load_path, start_epoch))
+        if ck.exists():
+            checkpoint = torch.load(ck, map_location=model.device, weights_only=True)
+            optimizer.load_state_dict(checkpoint["optimizer"])
+            if scheduler is not None and "lr_scheduler" in checkpoint:
+                scheduler.load_state_dict(checkpoint["lr_scheduler"])
+    return optimizer, scheduler
+
+
+def predict_batch(model, data, disentangle_keys=None):
+    """trainer.py:92-99 (plus the fused tail's inputs and optional injected noise)."""
+    keep = ["x6d", "root", "var", "offsets", "target_pose", "eps"]
+    data_i = {k: v for k, v in data.items() if (k in (disentangle_keys or [])) or (k in keep)}
+    return model(data_i)
+
+
+def train_test_epoch(config, model, loader, device, epoch, optimizer=None, scheduler=None, mode="train"):
+    """trainer.py:102-212."""
+    if mode == "train":
+        model.train()
+        grad_env = torch.enable_grad
+    elif mode == "test":
+        model.eval()
+        grad_env = torch.no_grad
+    else:
+        raise ValueError("This mode is not recognized.")
+    with grad_env():
+        model.mi_estimator = None
+        epoch_metrics = {k: 0 for k in ["total"] + list(config["loss"].keys())}
+        n_batches = 0
+        for batch_idx, data in enumerate(loader):
+            data = {k: v.to(device, non_blocking=True) for k, v in data.items()}
+            data_o = predict_batch(model, data, model.disentangle_keys)
+            # (the reference's adversarial `fit` branch compares mode to "Train" and never runs,
+            #  trainer.py:133 -- the discriminator stays at its initialisation)
+            batch_loss = get_batch_loss(model, data, data_o, config["loss"], config["disentangle"])
+            if mode == "train":
+                for param in model.parameters():
+                    param.grad = None
+                batch_loss["total"].backward()
+                clip_grad_norm_(model, max_norm=1e6)
+                optimizer.step()
+                if scheduler is not None:
+                    scheduler.step(epoch + batch_idx / len(loader))
+            epoch_metrics = {k: v + batch_loss[k].detach() for k, v in epoch_metrics.items()}
+            n_batches += 1
+        for k, v in epoch_metrics.items():
+            epoch_metrics[k] = (v.item() if torch.is_tensor(v) else float(v)) / max(n_batches, 1)
+            print("====> Epoch: {} Average {} loss: {:.4f}".format(epoch, k, epoch_metrics[k]))
+    return epoch_metrics
+
+
+def train_epoch(config, model, loader, optimizer, scheduler, device="cuda", epoch=0):
+    return train_test_epoch(config, model, loader, device, epoch, optimizer, scheduler, mode="train")
+
+
+def train(config, model, loader_dict, run=None):
+    """trainer.py:322-516 without the science-metric evaluation (sklearn decoders, clustering:
+    out of scope).  Keeps: optimizer/scheduler set-up, beta schedule, per-epoch
+    scrubber re-initialisation, weights every 5 epochs, optimizer state every 20."""
+    optimizer, scheduler = get_optimizer_and_lr_scheduler(
+        model, config["train"], config["model"].get("load_model"), config["model"].get("start_epoch"))
+    beta_scheduler = get_beta_schedule(config["loss"].get("prior"), config["train"].get("beta_anneal"))
+    start_epoch = config["model"].get("start_epoch") or 0
+    metrics = {}
+    for epoch in range(start_epoch + 1, config["train"]["num_epochs"] + 1):
+        if beta_scheduler is not None:
+            config["loss"]["prior"] = beta_scheduler.get(epoch)
+        t0 = time.time()
+        train_metrics = train_epoch(config, model, loader_dict["train"], optimizer, scheduler, model.device, epoch)
+        metrics = {"{}_train".format(k): v for k, v in train_metrics.items()}
+        metrics["time"] = time.time() - t0
+        if "grad_reversal" in model.disentangle.keys():
+            for k in model.disentangle["grad_reversal"].keys():
+                model.disentangle["grad_reversal"][k].reset_parameters()
+        if epoch % 5 == 0 and config.get("out_path"):
+            Path(config["out_path"] + "weights/").mkdir(parents=True, exist_ok=True)
+            torch.save({k: v.cpu() for k, v in model.state_dict().items()},
+                       "{}/weights/epoch_{}.pth".format(config["out_path"], epoch))
+            if epoch % 20 == 0:
+                Path(config["out_path"] + "checkpoints/").mkdir(parents=True, exist_ok=True)
+                ck = {"optimizer": optimizer.state_dict()}
+                if scheduler is not None:
+                    ck["lr_scheduler"] = scheduler.state_dict()
+                torch.save(ck, "{}/checkpoints/epoch_{}.pth".format(config["out_path"], epoch))
+        if run is not None:
+            run.log(metrics, epoch)
+    return model

@@ -27,8 +27,10 @@ SCENARIOS = {
     "vanilla_tiny": (O.OracleConfig(diag=True, **TINY), {"jpe": 1.0, "root": 1.0, "prior": 0.5}, "adamw"),
     "full_tiny": (O.OracleConfig(diag=True, method=FULL_METHODS, features=["avg_speed_3d", "heading"],
                                  discrete_classes={"ids": torch.arange(4)}, **TINY),
-                  {"jpe": 1.0, "root": 1.0, "prior": 0.5, "total_correlation": 0.1,
+                  {"jpe": 1.0, "root": 1.0, "prior": 0.5,
                    "avg_speed_3d_gr": 1.0, "heading_gr": 2.0, "heading_an": 0.5}, "adamw"),
+    "tc_tiny": (O.OracleConfig(diag=True, **TINY),
+                {"jpe": 1.0, "root": 1.0, "prior": 0.5, "total_correlation": 0.1}, "adamw"),
     "rotation_tiny": (O.OracleConfig(diag=True, **TINY),
                       {"jpe": 1.0, "root": 1.0, "prior": 0.5, "rotation": 0.01}, "adamw"),
     "fullL_ids_tiny": (O.OracleConfig(diag=False, method={"conditional": ["ids"], "grad_reversal": ["ids"]},
