@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Headline benchmark: pose-windows/sec through one full SC-VAE optimizer step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): synthetic 64-frame, 23-joint mouse skeletons, default
+residual-CNN channels [64,128,256,512,1024], z=32, batch 1024 per GPU, recon + KL
+(loss = {jpe, root, prior}), AdamW, fp32 compute (exact-fp32 MFMA).  A step = forward + all
+configured losses + backward + grad-norm + optimizer step, inputs already resident in HBM.
+Weak scaling: the per-GPU batch is fixed as N grows; every loss is normalised by the global
+batch, gradients are summed over ranks with RCCL and BatchNorm statistics are synchronised,
+so N ranks compute the 1-rank result at the global batch.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     -- the dominant kernel (fp32 MFMA implicit-GEMM), algorithmic FLOPs / launch
+                  over its mean launch time, measured live with HIP events in the timed region;
+  cpu_baseline -- the CPU oracle (oracle/scvae_oracle.py, stock PyTorch-CPU ops = the
+                  reference's own arithmetic) timed on this box's host cores on a bounded
+                  sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="windows per GPU")
+    ap.add_argument("--joints", type=int, default=23)
+    ap.add_argument("--window", type=int, default=64)
+    ap.add_argument("--full", action="store_true", help="configs[2]: conditional + grad-reversal + adversarial heads")
+    ap.add_argument("--local-bn", action="store_true", help="per-rank BatchNorm statistics (no sync-BN collectives)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--timer-kind", default="fwd", choices=["fwd", "dgrad", "wgrad"])
+    return ap.parse_args()
+
+
+CHANNELS = [64, 128, 256, 512, 1024]
+ARENA = [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]
+
+
+def make_cfg(args):
+    method, feats, loss = {}, [], {"jpe": 1.0, "root": 1.0, "prior": 1.0}
+    if args.full:
+        method = {"conditional": ["avg_speed_3d", "heading"], "grad_reversal": ["avg_speed_3d", "heading"],
+                  "adversarial_net": ["heading"]}
+        feats = ["avg_speed_3d", "heading"]
+        loss.update({"avg_speed_3d_gr": 1.0, "heading_gr": 1.0, "heading_an": 1.0})
+    return method, feats, loss
+
+
+def build_model(args, method, feats, tree):
+    from scrubvae_amd.get import model as get_model
+    mc = dict(type="rcnn", kernel=5, z_dim=32, window=args.window, activation="prelu", diag=True,
+              init_dilation=None, prior="gaussian", channel=CHANNELS)
+    dis = dict(method=method, alpha=1.0, features=feats)
+    torch.manual_seed(0)
+    m = get_model(mc, None, None, dis, args.joints, "midfwd", arena_size=torch.tensor(ARENA), kinematic_tree=tree,
+                  discrete_classes={"ids": torch.arange(4)} if args.full else None, device="cuda", verbose=0)
+    return m, dis
+
+
+def cpu_baseline(args, method, feats, loss, sample_b=128, steps=3):
+    """cpu_baseline leg: the CPU oracle's train_step (the only place bench.py touches oracle/)
+    on a bounded sample (sample_b windows) of the same workload."""
+    from oracle import scvae_oracle as O
+    cfg = O.OracleConfig(n_keypts=args.joints, window=args.window, z_dim=32, kernel=5, diag=True,
+                         arena_size=torch.tensor(ARENA), kinematic_tree=O.skeleton_tree(args.joints), method=method,
+                         features=feats, discrete_classes={"ids": torch.arange(4)} if args.full else None)
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = O.init_state_dict(cfg, seed=0)
+    data = O.synth_batch(cfg, sample_b, seed=0)
+    eps = torch.randn(sample_b, cfg.z_dim)
+    perm = {k: torch.randperm(sample_b) for k in cfg.method.get("adversarial_net", [])}
+    state = {}
+    O.train_step(sd, cfg, data, loss, eps, adv_perm=perm, opt_state=state)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, _, sd, _ = O.train_step(sd, cfg, data, loss, eps, adv_perm=perm, opt_state=state)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(sample_b / dt, 2), "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} optimizer steps of the CPU oracle at batch {sample_b} (same model/loss config), {dt*1e3:.0f} ms/step"}
+
+
+def main():
+    args = parse()
+    from scrubvae_amd import parallel, ops
+    from scrubvae_amd.train.losses import get_batch_loss
+    from scrubvae_amd.train.trainer import FusedAdam, clip_grad_norm_
+    rank, local, world = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    from scrubvae_amd.data import synthetic
+    method, feats, loss = make_cfg(args)
+    B = args.batch
+    data, tree = synthetic.make_batch(args.joints, args.window, B, seed=100 + rank, device="cuda")
+    model, dis = build_model(args, method, feats, tree)
+    parallel.attach(model, sync_bn=not args.local_bn)
+    opt = FusedAdam(model, lr=1e-4, weight_decay=0.01, decoupled=True)
+    model.train()
+
+    def step():
+        data_o = model(data)
+        bl = get_batch_loss(model, data, data_o, loss, dis)
+        bl["total"].backward()
+        clip_grad_norm_(model, 1e6)
+        opt.step()
+        return bl
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = None
+    if not args.no_roofline:
+        timer = ops.LaunchTimer(kinds=(args.timer_kind,), bn=128)
+        ops.TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bl = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tt)
+    total_loss = float(bl["total"])
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "pose-windows/sec (ELBO-match) on synthetic 64-frame mouse skeletons",
+            "value": round(B * world * args.steps / dt, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("configs[2] full SC-VAE (conditional + grad_reversal x2 + adversarial_net)" if args.full else
+                                    "configs[1] mouse-skeleton rcnn, recon+KL (jpe+root+prior), AdamW") +
+                                   f", batch {B}/GPU, window {args.window}, {args.joints} joints, z=32, channels [64,128,256,512,1024]",
+                       "batch_per_gpu": B, "global_batch": B * world, "window": args.window, "joints": args.joints,
+                       "parallelism": f"dp{world}" + ("" if world == 1 else ("+localbn" if args.local_bn else "+syncbn")),
+                       "final_total_loss": total_loss},
+        }
+        if timer is not None:
+            s = timer.summary().get(args.timer_kind)
+            if s and s["ms"] > 0:
+                tf = s["flops"] / (s["ms"] * 1e-3) / 1e12
+                kname = {"fwd": "gather_gemm_kernel<128,false>", "dgrad": "gather_gemm_kernel<128,true>",
+                         "wgrad": "wgrad_gemm_kernel<128> (+slab reduce)"}[args.timer_kind]
+                out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": kname,
+                                   "launches_per_step": s["launches"] // args.steps,
+                                   "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2),
+                                   "avg_launch_gflop": round(s["flops"] / s["launches"] / 1e9, 3)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, method, feats, loss)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -160,6 +160,8 @@ typedef struct {
  * `arena` is a HOST pointer to 6 floats (NULL: no root channels).
  * input_is_pre_tanh = 0: `y` already holds x_hat (no tanh, dy = d/dx_hat): the stand-alone
  * mpjpe_loss form.
+ * pose_out (optional) [rows, J, 3] receives pose_hat (used to synthesise target_pose and by
+ * the evaluation path).
  * loss_part [blocks][2].  dy may be NULL (eval: forward only).  ext_dx6d/ext_droot
  * (optional) are extra upstream grads w.r.t. x6d_hat/root_hat added before the tanh
  * backward (used by the rotation loss and by autograd callers). */
@@ -167,7 +169,7 @@ int svae_tail_blocks(long long rows);
 int svae_pose_tail(const float* y, int ld, const float* offsets, const float* target_pose,
                    const float* root, const float* arena, const svae_tree* tree,
                    float jpe_scale, float root_scale, const float* ext_dx6d, const float* ext_droot,
-                   float* x6d_hat, float* root_hat, float* loss_part, float* dy,
+                   float* x6d_hat, float* root_hat, float* loss_part, float* dy, float* pose_out,
                    long long rows, int input_is_pre_tanh, void* stream);
 
 /* L4: stable_rotation_loss (losses.py:123-136, rotation_conversion.py:469-488):

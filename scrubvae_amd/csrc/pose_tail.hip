@@ -26,6 +26,7 @@ struct TailArgs {
   float* root_hat;
   float* loss_part;
   float* dy;
+  float* pose_out;
   long long rows;
   int ld, J, ldt, ldo;
   int has_arena;
@@ -309,6 +310,14 @@ __global__ __launch_bounds__(64) void pose_tail_kernel(const TailArgs g) {
     g.loss_part[blockIdx.x * 2] = jpe;
     g.loss_part[blockIdx.x * 2 + 1] = rl;
   }
+  if (g.pose_out != nullptr) {
+    __syncthreads();
+    float* dp = g.pose_out + r0 * J3;
+    for (int e = lane; e < nrows * J3; e += 64) {
+      const int rr = e / J3, c = e - rr * J3;
+      dp[e] = pose[rr * ldo + c];
+    }
+  }
   if (do_bwd) {
     __syncthreads();
     const int f4_per_row = g.ld / 4;
@@ -427,7 +436,7 @@ extern "C" int svae_tail_blocks(long long rows) { return (int)((rows + 63) / 64)
 extern "C" int svae_pose_tail(const float* y, int ld, const float* offsets, const float* target_pose, const float* root,
                               const float* arena_host, const svae_tree* tree, float jpe_scale, float root_scale,
                               const float* ext_dx6d, const float* ext_droot, float* x6d_hat, float* root_hat, float* loss_part,
-                              float* dy, long long rows, int input_is_pre_tanh, void* stream) {
+                              float* dy, float* pose_out, long long rows, int input_is_pre_tanh, void* stream) {
   SVAE_REQUIRE(y && offsets && target_pose && tree && x6d_hat && loss_part && rows > 0, SVAE_ERR_ARG, "pose_tail: null pointer");
   const int J = tree->n_joints;
   SVAE_REQUIRE(J >= 1 && J <= SVAE_MAX_JOINTS && tree->n_chains >= 0 && tree->n_chains <= SVAE_MAX_CHAINS, SVAE_ERR_SHAPE,
@@ -452,7 +461,7 @@ extern "C" int svae_pose_tail(const float* y, int ld, const float* offsets, cons
   TailArgs g;
   memset(&g, 0, sizeof(g));
   g.y = y; g.offsets = offsets; g.target = target_pose; g.root = root; g.ext_dx6d = ext_dx6d; g.ext_droot = ext_droot;
-  g.x6d_hat = x6d_hat; g.root_hat = root_hat; g.loss_part = loss_part; g.dy = dy;
+  g.x6d_hat = x6d_hat; g.root_hat = root_hat; g.loss_part = loss_part; g.dy = dy; g.pose_out = pose_out;
   g.rows = rows; g.ld = ld; g.J = J;
   g.ldt = ld | 1;
   g.ldo = (3 * J) | 1;

@@ -274,6 +274,7 @@ class ResVAE(nn.Module):
         c = self._convs.get(key)
         if c is None:
             c = ops.Conv(batch, 1, p.in_lib, p.out_lib, 1, ld_in=ld_in, ld_out=ld_out)
+            c.flops = 2.0 * batch * p.in_f * p.out_f  # algorithmic: unpadded features
             self._convs[key] = c
         return c
 

@@ -32,11 +32,53 @@ def _f32c(t, name="tensor"):
         raise ValueError(f"{name}: expected a contiguous float32 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
 
 
+class LaunchTimer:
+    """Optional per-launch HIP-event timing of the GEMM kernels (bench.py's roofline leg).
+    Events are recorded on torch's current stream, which is the stream the kernels are
+    launched on.  kinds: subset of {"fwd", "dgrad", "wgrad"}; only launches whose kernel
+    template matches `bn` (64/128, None = any) are bracketed."""
+
+    def __init__(self, kinds=("fwd",), bn=128):
+        self.kinds, self.bn = set(kinds), bn
+        self.records = []  # (kind, flops, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, flops, s, e in self.records:
+            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += s.elapsed_time(e)
+        return out
+
+
+TIMER = None  # set to a LaunchTimer to enable
+
+
+def _tile_bn(n_padded):
+    w128, w64 = (n_padded + 127) // 128 * 128, (n_padded + 63) // 64 * 64
+    return 64 if w64 < w128 else 128
+
+
+def _timed(kind, conv, n_padded, fn):
+    t = TIMER
+    if t is None or kind not in t.kinds or (t.bn is not None and _tile_bn(n_padded) != t.bn):
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    t.records.append((kind, conv.flops, s, e))
+    return r
+
+
 class Conv:
     """Geometry of one nn.Conv1d / nn.ConvTranspose1d / nn.Linear call (padded channels)."""
 
     def __init__(self, batch, l_in, c_in, c_out, kernel, stride=1, padding=0, dilation=1, transposed=False,
                  ld_in=None, ld_out=None):
+        self.c_in, self.c_out = c_in, c_out
         self.c_in_p, self.c_out_p = pad16(c_in), pad16(c_out)
         if transposed:
             l_out = (l_in - 1) * stride - 2 * padding + dilation * (kernel - 1) + 1
@@ -48,6 +90,9 @@ class Conv:
                              ld_in or self.c_in_p, ld_out or self.c_out_p,
                              kernel, stride, padding, dilation, 1 if transposed else 0)
         self._ws_bytes = None
+        # algorithmic FLOPs of one pass (forward = dgrad = wgrad): 2*B*L*k*Cin*Cout with the
+        # unpadded channel counts, L = output length (conv) / input length (transposed conv)
+        self.flops = 2.0 * batch * (l_in if transposed else l_out) * kernel * c_in * c_out
 
     @property
     def weight_shape(self):
@@ -59,16 +104,19 @@ class Conv:
         return self._ws_bytes
 
     def fwd(self, x, w, bias, y, accumulate=False):
-        check(_lib.lib().svae_conv_fwd(C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), int(accumulate), _stream()), "conv_fwd")
+        _timed("fwd", self, self.c_out_p, lambda: check(_lib.lib().svae_conv_fwd(
+            C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), int(accumulate), _stream()), "conv_fwd"))
         return y
 
     def dgrad(self, dy, w, dx, accumulate=False):
-        check(_lib.lib().svae_conv_dgrad(C.byref(self.desc), _p(dy), _p(w), _p(dx), int(accumulate), _stream()), "conv_dgrad")
+        _timed("dgrad", self, self.c_in_p, lambda: check(_lib.lib().svae_conv_dgrad(
+            C.byref(self.desc), _p(dy), _p(w), _p(dx), int(accumulate), _stream()), "conv_dgrad"))
         return dx
 
     def wgrad(self, x, dy, dw, db, ws, accumulate=False):
-        check(_lib.lib().svae_conv_wgrad(C.byref(self.desc), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
-                                         ws.numel() * ws.element_size(), int(accumulate), _stream()), "conv_wgrad")
+        _timed("wgrad", self, self.c_out_p, lambda: check(_lib.lib().svae_conv_wgrad(
+            C.byref(self.desc), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel() * ws.element_size(), int(accumulate),
+            _stream()), "conv_wgrad"))
 
 
 # ----------------------------------------------------------------- weight layout (TIO)
@@ -194,10 +242,10 @@ def tail_blocks(rows):
 
 
 def pose_tail(y, ld, offsets, target, root, arena_host, tree, jpe_scale, root_scale, ext_dx6d, ext_droot,
-              x6d_hat, root_hat, loss_part, dy, rows, pre_tanh=True):
+              x6d_hat, root_hat, loss_part, dy, rows, pre_tanh=True, pose_out=None):
     check(_lib.lib().svae_pose_tail(_p(y), ld, _p(offsets), _p(target), _p(root), _arena_ptr(arena_host), C.byref(tree),
                                     float(jpe_scale), float(root_scale), _p(ext_dx6d), _p(ext_droot), _p(x6d_hat), _p(root_hat),
-                                    _p(loss_part), _p(dy), rows, int(pre_tanh), _stream()), "pose_tail")
+                                    _p(loss_part), _p(dy), _p(pose_out), rows, int(pre_tanh), _stream()), "pose_tail")
 
 
 def rot_blocks(n):
