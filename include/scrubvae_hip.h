@@ -74,6 +74,9 @@ size_t svae_conv_wgrad_workspace(const svae_conv_desc* d);
 int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const float* dy, float* dw,
                     float* db, void* ws, size_t ws_bytes, int accumulate, void* stream);
 
+/* introspection: the (BM, BN) workgroup tile the dispatcher uses; kind 0 fwd, 1 dgrad, 2 wgrad */
+int svae_conv_tile(const svae_conv_desc* d, int kind, int* bm, int* bn);
+
 /* ------------------------------------------------------------- elementwise / norm --- */
 /* E0: ResVAE.normalize_root + input pack (residual.py:428-431,438-451).
  * x6d [rows, 6J], root [rows,3], arena = HOST pointer to 6 floats [2,3] (may be NULL:

@@ -52,6 +52,7 @@ SIGNATURES = {
     "svae_conv_dgrad": (I, [DP, P, P, P, I, P]),
     "svae_conv_wgrad_workspace": (SZ, [DP]),
     "svae_conv_wgrad": (I, [DP, P, P, P, P, P, SZ, I, P]),
+    "svae_conv_tile": (I, [DP, I, C.POINTER(I), C.POINTER(I)]),
     "svae_pack_input": (I, [P, P, C.POINTER(F), P, LL, I, I, P]),
     "svae_bn_chunks": (I, [LL]),
     "svae_bn_stats_partial": (I, [P, LL, I, I, P, P]),
@@ -95,6 +96,9 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  scrubvae_amd has no CPU fallback.")
+        # PyTorch-ROCm ships its own libamdhip64: load it FIRST so that this library binds to
+        # the same HIP runtime instance (two runtimes in one process cannot share pointers)
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library does not export it

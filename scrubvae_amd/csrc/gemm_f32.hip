@@ -27,7 +27,6 @@ namespace svae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;
 constexpr int BK = 16;
 constexpr int LDK = BK + 4;  // padded row of a K-contiguous LDS tile (conflict-free b128)
 
@@ -53,8 +52,11 @@ struct GatherArgs {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-template <int BN, bool B_KC>
+template <int BM, int BN, bool B_KC>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
+  constexpr int WM = BM / 2;   // wave tile rows
+  constexpr int MT = WM / 32;  // MFMA tiles down
+  constexpr int APASS = BM / 64;
   constexpr int WN = BN / 2;   // wave tile columns
   constexpr int NT = WN / 32;  // MFMA tiles across
   constexpr int B_ELEMS = B_KC ? BN * LDK : BK * BN;
@@ -76,10 +78,10 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
 
   // ---- per-thread A rows (2 rows, one 16-byte column slot each)
   const int akq = tid & 3;
-  long long a_off[2];
-  int a_j[2];
+  long long a_off[APASS];
+  int a_j[APASS];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < APASS; ++i) {
     const long long m = m0 + (tid >> 2) + 64 * i;
     if (m < Mp) {
       const long long b = m / nj;
@@ -105,14 +107,27 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
   const int tiles_per_tap = g.Kc / BK;
   const int nk = ntaps * tiles_per_tap;
 
-  float4 ra[2], rb[BPASS];
-  auto load_tile = [&](int kt) {
-    const int ti = kt / tiles_per_tap;
-    const int c0 = (kt - ti * tiles_per_tap) * BK;
-    const int tb = tap_base[ti];
-    const float* wt = g.W + (long long)tap_w[ti] * g.w_tap_stride;
+  float4 ra[APASS], rb[BPASS];
+  // tap bookkeeping is advanced incrementally and one tile AHEAD of its use, so that the
+  // scalar loads of the tap table never sit in front of the global loads / MFMAs
+  int nx_c0 = 0, nx_ti = 0;
+  int nx_tb = ntaps > 0 ? tap_base[0] : 0;
+  long long nx_woff = ntaps > 0 ? (long long)tap_w[0] * g.w_tap_stride : 0;
+  auto load_tile = [&]() {
+    const int c0 = nx_c0;
+    const int tb = nx_tb;
+    const float* wt = g.W + nx_woff;
+    nx_c0 += BK;
+    if (nx_c0 == g.Kc) {
+      nx_c0 = 0;
+      ++nx_ti;
+      if (nx_ti < ntaps) {
+        nx_tb = tap_base[nx_ti];
+        nx_woff = (long long)tap_w[nx_ti] * g.w_tap_stride;
+      }
+    }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < APASS; ++i) {
       const int li = a_j[i] + tb;
       if (li >= 0 && li < g.Lin)
         ra[i] = ld4(g.A + a_off[i] + (long long)li * g.ldA + c0);
@@ -144,7 +159,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) st4(&As[buf][((tid >> 2) + 64 * i) * LDK + akq * 4], ra[i]);
+    for (int i = 0; i < APASS; ++i) st4(&As[buf][((tid >> 2) + 64 * i) * LDK + akq * 4], ra[i]);
     if constexpr (B_KC) {
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) st4(&Bs[buf][((tid >> 2) + 64 * i) * LDK + akq * 4], rb[i]);
@@ -161,47 +176,53 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 31, h = lane >> 5;
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (nk > 0) {
-    load_tile(0);
+    load_tile();
     store_tile(0);
   }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < nk) load_tile();
     const float* as = As[buf];
     const float* bs = Bs[buf];
+    // all LDS fragment reads of the K tile are issued up front (32 VGPRs); the MFMAs then
+    // start as soon as the first fragments land and the rest arrive under them
+    float4 av[2][MT], bv[2][NT];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      float4 av[2], bv[NT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) av[mt] = ld4(&as[(wr * 64 + mt * 32 + lr) * LDK + q * 8 + h * 4]);
+      for (int mt = 0; mt < MT; ++mt) av[q][mt] = ld4(&as[(wr * WM + mt * 32 + lr) * LDK + q * 8 + h * 4]);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if constexpr (B_KC) {
-          bv[nt] = ld4(&bs[(wc * WN + nt * 32 + lr) * LDK + q * 8 + h * 4]);
+          bv[q][nt] = ld4(&bs[(wc * WN + nt * 32 + lr) * LDK + q * 8 + h * 4]);
         } else {
           const float* p = &bs[(q * 8 + h * 4) * BN + wc * WN + nt * 32 + lr];
-          bv[nt] = make_float4(p[0], p[BN], p[2 * BN], p[3 * BN]);
+          bv[q][nt] = make_float4(p[0], p[BN], p[2 * BN], p[3 * BN]);
         }
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const float a = jj == 0 ? av[mt].x : jj == 1 ? av[mt].y : jj == 2 ? av[mt].z : av[mt].w;
+        for (int mt = 0; mt < MT; ++mt) {
+          const float a = jj == 0 ? av[q][mt].x : jj == 1 ? av[q][mt].y : jj == 2 ? av[q][mt].z : av[q][mt].w;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            const float b = jj == 0 ? bv[nt].x : jj == 1 ? bv[nt].y : jj == 2 ? bv[nt].z : bv[nt].w;
+            const float b = jj == 0 ? bv[q][nt].x : jj == 1 ? bv[q][nt].y : jj == 2 ? bv[q][nt].z : bv[q][nt].w;
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
           }
         }
@@ -218,10 +239,10 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
     if (col >= g.N) continue;
     const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int row = wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const long long off = rowoff[row];
         if (off >= 0) {
           float* dst = g.C + off + col;
@@ -244,12 +265,17 @@ struct WgradArgs {
   long long slab_stride;
   int nj, Lx, Ly, sx, sy;
   int bx[SVAE_MAX_TAPS], by[SVAE_MAX_TAPS];
-  int T, Kc, N, ldX, ldY, ldW, ctiles;
+  int T, Kc, N, ldX, ldY, ldW, ctiles, bm;
   int accumulate;
 };
 
-template <int BN>
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
+  constexpr int WM = BM / 2;
+  constexpr int MT = WM / 32;
+  constexpr int APASS = BM / 64;
+  constexpr int AF4_PER_ROW = BM / 4;
+  constexpr int AROWS_PER_PASS = 256 / AF4_PER_ROW;
   constexpr int WN = BN / 2;
   constexpr int NT = WN / 32;
   constexpr int BPASS = BN / 64;
@@ -265,45 +291,62 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
   if (r_end > g.R) r_end = g.R;
   const int tbx = g.bx[ti], tby = g.by[ti];
 
-  const int a_c = c0 + (tid & 31) * 4;  // 32 float4 per k-row of A
-  const int a_r = tid >> 5;             // 8 rows per pass, 2 passes
+  const int a_c = c0 + (tid % AF4_PER_ROW) * 4;
+  const int a_r = tid / AF4_PER_ROW;
   constexpr int F4_PER_ROW = BN / 4;
   constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
   const int b_n = n0 + (tid % F4_PER_ROW) * 4;
   const int b_r = tid / F4_PER_ROW;
 
-  float4 ra[2], rb[BPASS];
+  float4 ra[APASS], rb[BPASS];
+  // reduction rows advance by BK per tile: (batch, position) of each staged row is kept
+  // incrementally (no division in the loop)
+  const int q16 = BK / g.nj, r16 = BK % g.nj;
+  long long a_b[APASS], b_b[BPASS];
+  int a_jj[APASS], b_jj[BPASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const long long r = r_begin + a_r + AROWS_PER_PASS * i;
+    a_b[i] = r / g.nj;
+    a_jj[i] = (int)(r - a_b[i] * g.nj);
+  }
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    const long long r = r_begin + b_r + ROWS_PER_PASS * i;
+    b_b[i] = r / g.nj;
+    b_jj[i] = (int)(r - b_b[i] * g.nj);
+  }
   auto load_tile = [&](long long r0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const long long r = r0 + a_r + 8 * i;
+    for (int i = 0; i < APASS; ++i) {
+      const long long r = r0 + a_r + AROWS_PER_PASS * i;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < r_end && a_c < g.Kc) {
-        const long long b = r / g.nj;
-        const int j = (int)(r - b * g.nj);
-        const int xr = j * g.sx + tbx;
-        const int yr = j * g.sy + tby;
-        if (xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly) v = ld4(g.X + (b * g.Lx + xr) * (long long)g.ldX + a_c);
+        const int xr = a_jj[i] * g.sx + tbx;
+        const int yr = a_jj[i] * g.sy + tby;
+        if (xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly) v = ld4(g.X + (a_b[i] * g.Lx + xr) * (long long)g.ldX + a_c);
       }
       ra[i] = v;
+      a_jj[i] += r16; a_b[i] += q16;
+      if (a_jj[i] >= g.nj) { a_jj[i] -= g.nj; ++a_b[i]; }
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
       const long long r = r0 + b_r + ROWS_PER_PASS * i;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < r_end && b_n < g.N) {
-        const long long b = r / g.nj;
-        const int j = (int)(r - b * g.nj);
-        const int xr = j * g.sx + tbx;
-        const int yr = j * g.sy + tby;
-        if (xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly) v = ld4(g.dY + (b * g.Ly + yr) * (long long)g.ldY + b_n);
+        const int xr = b_jj[i] * g.sx + tbx;
+        const int yr = b_jj[i] * g.sy + tby;
+        if (xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly) v = ld4(g.dY + (b_b[i] * g.Ly + yr) * (long long)g.ldY + b_n);
       }
       rb[i] = v;
+      b_jj[i] += r16; b_b[i] += q16;
+      if (b_jj[i] >= g.nj) { b_jj[i] -= g.nj; ++b_b[i]; }
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) st4(&As[buf][(a_r + 8 * i) * BM + (tid & 31) * 4], ra[i]);
+    for (int i = 0; i < APASS; ++i) st4(&As[buf][(a_r + AROWS_PER_PASS * i) * BM + (tid % AF4_PER_ROW) * 4], ra[i]);
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) st4(&Bs[buf][(b_r + ROWS_PER_PASS * i) * BN + (tid % F4_PER_ROW) * 4], rb[i]);
   };
@@ -312,9 +355,9 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 31, h = lane >> 5;
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -331,24 +374,26 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
     if (kt + 1 < nk) load_tile(r_begin + (long long)(kt + 1) * BK);
     const float* as = As[buf];
     const float* bs = Bs[buf];
+    float av[2][MT][4], bv[2][NT][4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      float av[2][4], bv[NT][4];
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) av[mt][jj] = as[(q * 8 + h * 4 + jj) * BM + wr * 64 + mt * 32 + lr];
+        for (int mt = 0; mt < MT; ++mt) av[q][mt][jj] = as[(q * 8 + h * 4 + jj) * BM + wr * WM + mt * 32 + lr];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt][jj] = bs[(q * 8 + h * 4 + jj) * BN + wc * WN + nt * 32 + lr];
+        for (int nt = 0; nt < NT; ++nt) bv[q][nt][jj] = bs[(q * 8 + h * 4 + jj) * BN + wc * WN + nt * 32 + lr];
       }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][jj], bv[nt][jj], acc[mt][nt], 0, 0, 0);
-    }
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][mt][jj], bv[q][nt][jj], acc[mt][nt], 0, 0, 0);
     if (kt + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();
   }
@@ -359,10 +404,10 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
     const int col = n0 + wc * WN + nt * 32 + lr;
     if (col >= g.N) continue;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = c0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int c = c0 + wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (c < g.Kc) {
           float* dst = out + (long long)c * g.ldW + col;
           float v = acc[mt][nt][r];
@@ -473,29 +518,50 @@ static void build_plan(GatherArgs& g, const svae_conv_desc* d, bool strided, int
       g.ntaps[p] = n;
     }
   }
-  for (int p = 0; p < g.n_phase; ++p) {
-    g.M[p] = (long long)d->batch * g.nj[p];
-    g.blocks_m[p] = (int)((g.M[p] + BM - 1) / BM);
-  }
+  for (int p = 0; p < g.n_phase; ++p) g.M[p] = (long long)d->batch * g.nj[p];
 }
 
-// choose the 64-wide tile when it wastes fewer columns (e.g. N=144: 3x64=192 vs 2x128=256)
-static bool prefer_bn64(int N) {
-  const int w128 = ((N + 127) / 128) * 128, w64 = ((N + 63) / 64) * 64;
-  return w64 < w128;
+// ---- tile selection.  Per-block work is MFMA-bound and co-resident blocks hide each other's
+// barrier / LDS-fill stalls, so prefer the largest tile that still gives >= 2 blocks per CU;
+// below that, more (smaller) blocks win.  Scores are relative throughput estimates.
+struct Tile { int bm, bn; };
+
+static double tile_score(long long M0, long long M1, int N, int bm, int bn) {
+  const long long bmk = (M0 + bm - 1) / bm + (M1 + bm - 1) / bm;
+  const long long bnk = (N + bn - 1) / bn;
+  const long long blocks = bmk * bnk;
+  if (blocks == 0) return 0.0;
+  const double useful = (double)(M0 + M1) * N / ((double)bmk * bm * bnk * bn);
+  const double resident = 256.0 * (bm * bn >= 128 * 128 ? 2.0 : 3.0);  // blocks the chip holds at once
+  const double waves = (double)((blocks + (long long)resident - 1) / (long long)resident);
+  const double fill = (double)blocks / (waves * resident);
+  const double occ = blocks >= 512 ? 1.0 : (blocks >= 256 ? 0.8 : 0.8 * blocks / 256.0);
+  const double teff = (bm * bn >= 128 * 128) ? 1.0 : (bm * bn >= 64 * 128 ? 0.93 : 0.85);
+  return useful * teff * occ * (0.5 + 0.5 * fill);
+}
+
+static Tile pick_tile(long long M0, long long M1, int N) {
+  const Tile cand[4] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  Tile best = cand[0];
+  double bs = -1.0;
+  for (const Tile& t : cand) {
+    const double sc = tile_score(M0, M1, N, t.bm, t.bn);
+    if (sc > bs * 1.001) { bs = sc; best = t; }
+  }
+  return best;
 }
 
 template <bool B_KC>
 static int launch_gather_auto(GatherArgs& g, hipStream_t st) {
+  const Tile t = pick_tile(g.M[0], g.M[1], g.N);
+  for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + t.bm - 1) / t.bm);
   const int bm = g.blocks_m[0] + g.blocks_m[1];
   if (bm == 0) return SVAE_OK;
-  if (prefer_bn64(g.N)) {
-    dim3 grid(bm, (g.N + 63) / 64);
-    hipLaunchKernelGGL((gather_gemm_kernel<64, B_KC>), grid, dim3(256), 0, st, g);
-  } else {
-    dim3 grid(bm, (g.N + 127) / 128);
-    hipLaunchKernelGGL((gather_gemm_kernel<128, B_KC>), grid, dim3(256), 0, st, g);
-  }
+  dim3 grid(bm, (g.N + t.bn - 1) / t.bn);
+  if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, B_KC>), grid, dim3(256), 0, st, g);
+  else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((gather_gemm_kernel<128, 64, B_KC>), grid, dim3(256), 0, st, g);
+  else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((gather_gemm_kernel<64, 128, B_KC>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gather_gemm_kernel<64, 64, B_KC>), grid, dim3(256), 0, st, g);
   return check_launch("gather_gemm");
 }
 
@@ -537,27 +603,41 @@ extern "C" int svae_conv_dgrad(const svae_conv_desc* d, const float* dy, const f
 }
 
 namespace svae {
-static void wgrad_geometry(const svae_conv_desc* d, int& nsplit, long long& rps, long long& R, int& nj) {
-  nj = d->transposed ? d->l_in : d->l_out;
-  R = (long long)d->batch * nj;
-  const int bn = prefer_bn64(d->c_out) ? 64 : 128;
-  const long long tiles = (long long)d->kernel * ((d->c_in + BM - 1) / BM) * ((d->c_out + bn - 1) / bn);
-  long long want = (1536 + tiles - 1) / tiles;
-  long long maxs = (R + 255) / 256;  // at least 256 reduction rows per split
+struct WgradGeo { int bm, bn, nsplit, nj, ctiles; long long rps, R; };
+
+static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
+  WgradGeo w;
+  w.nj = d->transposed ? d->l_in : d->l_out;
+  w.R = (long long)d->batch * w.nj;
+  // tile rows run over the input channels of ONE tap: 64-row tiles when c_in has no 128 multiple
+  w.bm = (d->c_in % 128 == 0) ? 128 : 64;
+  const int w128 = ((d->c_out + 127) / 128) * 128, w64 = ((d->c_out + 63) / 64) * 64;
+  w.bn = (w64 < w128) ? 64 : 128;
+  w.ctiles = (d->c_in + w.bm - 1) / w.bm;
+  long long tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
+  if (w.bm == 128 && w.bn == 128 && tiles < 256 && w.R < 16384) {  // few, short tiles: go finer
+    w.bm = 64;
+    w.ctiles = (d->c_in + 63) / 64;
+    tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
+  }
+  // resident blocks: 3 per CU for the 128x128 tile (144 VGPR+AGPR), 4 for the smaller ones
+  const long long slots = 256 * ((w.bm == 128 && w.bn == 128) ? 3 : 4);
+  long long want = tiles >= slots ? 1 : slots / tiles;
+  const long long maxs = (w.R + 127) / 128;  // at least 128 reduction rows per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
-  if (want > 256) want = 256;
-  rps = (R + want - 1) / want;
-  rps = ((rps + BK - 1) / BK) * BK;
-  nsplit = (int)((R + rps - 1) / rps);
+  if (want > 512) want = 512;
+  w.rps = (w.R + want - 1) / want;
+  w.rps = ((w.rps + BK - 1) / BK) * BK;
+  w.nsplit = (int)((w.R + w.rps - 1) / w.rps);
+  return w;
 }
 }  // namespace svae
 
 extern "C" size_t svae_conv_wgrad_workspace(const svae_conv_desc* d) {
   if (validate(d)) return 0;
-  int nsplit, nj;
-  long long rps, R;
-  wgrad_geometry(d, nsplit, rps, R, nj);
+  const WgradGeo wg = wgrad_geometry(d);
+  const int nsplit = wg.nsplit;
   const long long rows = (long long)d->batch * d->l_out;
   const long long chunks = (rows + COLSUM_ROWS - 1) / COLSUM_ROWS;
   size_t slab = nsplit > 1 ? (size_t)nsplit * d->kernel * d->c_in * d->c_out : 0;
@@ -573,17 +653,17 @@ extern "C" int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const fl
   SVAE_REQUIRE(ws_bytes >= svae_conv_wgrad_workspace(d), SVAE_ERR_WORKSPACE, "conv_wgrad: workspace %zu < %zu", ws_bytes,
                svae_conv_wgrad_workspace(d));
   hipStream_t st = (hipStream_t)stream;
-  int nsplit, nj;
-  long long rps, R;
-  wgrad_geometry(d, nsplit, rps, R, nj);
+  const WgradGeo wg = wgrad_geometry(d);
+  const int nsplit = wg.nsplit;
   WgradArgs g;
   memset(&g, 0, sizeof(g));
   g.X = x; g.dY = dy;
-  g.R = R; g.rows_per_split = rps; g.nj = nj;
+  g.R = wg.R; g.rows_per_split = wg.rps; g.nj = wg.nj;
   g.Lx = d->l_in; g.Ly = d->l_out;
   g.T = d->kernel; g.Kc = d->c_in; g.N = d->c_out;
   g.ldX = d->ld_in; g.ldY = d->ld_out; g.ldW = d->c_out;
-  g.ctiles = (d->c_in + BM - 1) / BM;
+  g.ctiles = wg.ctiles;
+  g.bm = wg.bm;
   for (int t = 0; t < d->kernel; ++t) {
     if (!d->transposed) { g.bx[t] = t * d->dilation - d->padding; g.by[t] = 0; }
     else { g.bx[t] = 0; g.by[t] = t * d->dilation - d->padding; }
@@ -594,10 +674,11 @@ extern "C" int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const fl
   float* slab = (float*)ws;
   if (nsplit > 1) { g.out = slab; g.slab_stride = wsize; g.accumulate = 0; }
   else { g.out = dw; g.slab_stride = 0; g.accumulate = accumulate; }
-  const bool bn64 = prefer_bn64(d->c_out);
-  dim3 grid(d->kernel * g.ctiles, bn64 ? (d->c_out + 63) / 64 : (d->c_out + 127) / 128, nsplit);
-  if (bn64) hipLaunchKernelGGL((wgrad_gemm_kernel<64>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((wgrad_gemm_kernel<128>), grid, dim3(256), 0, st, g);
+  dim3 grid(d->kernel * g.ctiles, (d->c_out + wg.bn - 1) / wg.bn, nsplit);
+  if (wg.bm == 128 && wg.bn == 128) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128>), grid, dim3(256), 0, st, g);
+  else if (wg.bm == 128 && wg.bn == 64) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 64>), grid, dim3(256), 0, st, g);
+  else if (wg.bm == 64 && wg.bn == 128) hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64>), grid, dim3(256), 0, st, g);
   if (int e = check_launch("wgrad_gemm")) return e;
   if (nsplit > 1) {
     const long long n4 = wsize / 4;
@@ -617,5 +698,23 @@ extern "C" int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const fl
                        accumulate);
     if (int e = check_launch("colsum_final")) return e;
   }
+  return SVAE_OK;
+}
+
+// which tile the dispatcher picks for this problem (bench.py names the kernel template with it)
+extern "C" int svae_conv_tile(const svae_conv_desc* d, int kind, int* bm, int* bn) {
+  if (int e = validate(d)) return e;
+  SVAE_REQUIRE(bm && bn && kind >= 0 && kind <= 2, SVAE_ERR_ARG, "conv_tile: bad args");
+  if (kind == 2) {
+    const WgradGeo wg = wgrad_geometry(d);
+    *bm = wg.bm; *bn = wg.bn;
+    return SVAE_OK;
+  }
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  if (kind == 0) { g.N = d->c_out; build_plan(g, d, !d->transposed, d->l_out, d->l_in); }
+  else { g.N = d->c_in; build_plan(g, d, d->transposed != 0, d->l_in, d->l_out); }
+  const Tile t = pick_tile(g.M[0], g.M[1], g.N);
+  *bm = t.bm; *bn = t.bn;
   return SVAE_OK;
 }

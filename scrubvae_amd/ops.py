@@ -38,11 +38,12 @@ class LaunchTimer:
     launched on.  kinds: subset of {"fwd", "dgrad", "wgrad"}; only launches whose kernel
     template matches `bn` (64/128, None = any) are bracketed."""
 
-    def __init__(self, kinds=("fwd",), bn=128):
-        self.kinds, self.bn = set(kinds), bn
-        self.records = []  # (kind, flops, start_event, end_event)
+    def __init__(self, kinds=("fwd",)):
+        self.kinds = set(kinds)
+        self.records = []  # (kernel template name, flops, start_event, end_event)
 
     def summary(self):
+        """kernel name -> launches, algorithmic flops, total ms."""
         torch.cuda.synchronize()
         out = {}
         for kind, flops, s, e in self.records:
@@ -56,20 +57,18 @@ class LaunchTimer:
 TIMER = None  # set to a LaunchTimer to enable
 
 
-def _tile_bn(n_padded):
-    w128, w64 = (n_padded + 127) // 128 * 128, (n_padded + 63) // 64 * 64
-    return 64 if w64 < w128 else 128
+_KIND_ID = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 
 
 def _timed(kind, conv, n_padded, fn):
     t = TIMER
-    if t is None or kind not in t.kinds or (t.bn is not None and _tile_bn(n_padded) != t.bn):
+    if t is None or kind not in t.kinds:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = fn()
     e.record()
-    t.records.append((kind, conv.flops, s, e))
+    t.records.append((conv.kernel_name(kind), conv.flops, s, e))
     return r
 
 
@@ -93,6 +92,18 @@ class Conv:
         # algorithmic FLOPs of one pass (forward = dgrad = wgrad): 2*B*L*k*Cin*Cout with the
         # unpadded channel counts, L = output length (conv) / input length (transposed conv)
         self.flops = 2.0 * batch * (l_in if transposed else l_out) * kernel * c_in * c_out
+
+    def kernel_name(self, kind):
+        """Name of the kernel template instance this call dispatches to (as rocprofv3 prints it)."""
+        names = self.__dict__.setdefault("_names", {})
+        if kind not in names:
+            bm, bn = C.c_int(), C.c_int()
+            check(_lib.lib().svae_conv_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn)), "conv_tile")
+            if kind == "wgrad":
+                names[kind] = f"wgrad_gemm_kernel<{bm.value}, {bn.value}>"
+            else:
+                names[kind] = f"gather_gemm_kernel<{bm.value}, {bn.value}, {'true' if kind == 'dgrad' else 'false'}>"
+        return names[kind]
 
     @property
     def weight_shape(self):
