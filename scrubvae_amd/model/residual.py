@@ -289,7 +289,13 @@ class ResVAE(nn.Module):
     def _allreduce(self, t):
         if self.world_size > 1:
             import torch.distributed as dist
-            dist.all_reduce(t, group=self.process_group)
+            if t.is_cuda and dist.get_backend(self.process_group) == "gloo":
+                # test configuration (several ranks sharing one GPU): stage through the host
+                h = t.detach().cpu()
+                dist.all_reduce(h, group=self.process_group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, group=self.process_group)
 
     # ------------------------------------------------------------------ BN + PReLU stage
     def _bn_act(self, tag, x, bn: BatchNormP, act: PReLUP, rows, out):

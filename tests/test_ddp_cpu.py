@@ -1,0 +1,120 @@
+"""N>1 path on CPU: world_size-2 gloo runs of the data-parallel protocol
+(scrubvae_amd/parallel.py) with the CPU oracle as the compute stand-in.
+
+Checks (a) shard_range partitions exactly, (b) the sync-BN statistic exchange reproduces the
+global batch statistics, (c) "every loss normalised by the GLOBAL batch + SUM all-reduce of
+gradients" reproduces the single-process gradients of the global batch.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import scvae_oracle as O
+from scrubvae_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_range_partitions():
+    for n in (1, 7, 8, 1024, 1025):
+        for w in (1, 2, 3, 8):
+            spans = [parallel.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    parallel.init_distributed(backend="gloo")
+    try:
+        # (b) sync-BN statistics
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(64, 10, generator=g, dtype=torch.float64) * 3 + 1
+        lo, hi = parallel.shard_range(64, rank, world)
+        xs = x[lo:hi]
+        sums, count = parallel.bn_sync_stats(torch.stack([xs.sum(0), (xs * xs).sum(0)]), hi - lo)
+        mean = sums[0] / count
+        var = sums[1] / count - mean ** 2
+        ok_bn = torch.allclose(mean, x.mean(0)) and torch.allclose(var, x.var(0, unbiased=False))
+        # (c) gradient protocol with the oracle (eval-mode BN: no cross-sample coupling left
+        # except through the normalisation by the global batch)
+        arena = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], dtype=torch.float64)
+        cfg = O.OracleConfig(n_keypts=18, window=64, z_dim=8, kernel=5, channel=(8, 8, 16, 16, 32), diag=True, arena_size=arena)
+        sd = O.init_state_dict(cfg, seed=2, dtype=torch.float64)
+        data = O.synth_batch(cfg, 8, seed=2, dtype=torch.float64)
+        ls = {"jpe": 1.0, "root": 1.0, "prior": 0.5}
+        names = O.trainable_names(sd)
+
+        def grads_of(batch, global_b):
+            leaf = {n: sd[n].clone().requires_grad_(True) for n in names}
+            work = dict(sd); work.update(leaf)
+            out = O.forward(work, cfg, batch, False)
+            bl = O.batch_loss(work, cfg, batch, out, ls)
+            local_b = batch["x6d"].shape[0]
+            (bl["total"] * local_b / global_b).backward()  # normalise by the GLOBAL batch
+            return torch.cat([leaf[n].grad.flatten() if leaf[n].grad is not None else torch.zeros_like(leaf[n]).flatten() for n in names])
+
+        shard = {k: v[slice(*parallel.shard_range(8, rank, world))] for k, v in data.items()}
+        gflat = parallel.allreduce_sum_(grads_of(shard, 8))
+        ok_grad = True
+        if rank == 0:
+            ref = grads_of(data, 8)
+            ok_grad = bool(torch.allclose(gflat, ref, rtol=1e-9, atol=1e-12))
+        if rank == 0:
+            q.put((ok_bn, ok_grad))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_protocol():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok_bn, ok_grad = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok_bn and ok_grad
+
+
+def test_capi_exports_every_declared_symbol():
+    """The C-ABI library loads on a GPU-less host and exports every symbol include/*.h declares."""
+    import re
+    from scrubvae_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "scrubvae_hip.h")).read()
+    declared = set(re.findall(r"\b(svae_[a-z0-9_]+)\s*\(", header))
+    declared -= {"svae_status"}
+    lib = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in scrubvae_amd/_lib.py"
+    assert lib.svae_version() >= 100
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under scrubvae_amd/ may import it."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scrubvae_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("scvae_oracle", "oracle").split("import")[-1] or "from oracle" not in src, f
+                assert "from oracle" not in src and "import oracle" not in src, f
