@@ -65,7 +65,8 @@ def _worker(rank, world, port, q):
         lt = torch.tensor([losses[k] for k in sorted(losses)], dtype=torch.float64)
         dist.all_reduce(lt)
         if rank == 0:
-            q.put((dict(zip(sorted(losses), lt.tolist())), grads, stats))
+            # numpy (pickled by value): torch tensors would be shared through fds of a process that exits
+            q.put((dict(zip(sorted(losses), lt.tolist())), grads.numpy(), {k: v.numpy() for k, v in stats.items()}))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -83,6 +84,8 @@ def test_two_ranks_match_one_rank():
     for p in procs:
         p.start()
     losses, grads, stats = q.get(timeout=300)
+    grads = torch.from_numpy(grads)
+    stats = {k: torch.from_numpy(v) for k, v in stats.items()}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
