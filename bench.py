@@ -111,6 +111,7 @@ def main():
     data, tree = synthetic.make_batch(args.joints, args.window, B, seed=100 + rank, device="cuda")
     model, dis = build_model(args, method, feats, tree)
     parallel.attach(model, sync_bn=not args.local_bn)
+    model.defer_tail = True  # one fused tail launch per step (outputs + losses + seed gradients)
     opt = FusedAdam(model, lr=1e-4, weight_decay=0.01, decoupled=True)
     model.train()
 

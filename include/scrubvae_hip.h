@@ -58,6 +58,10 @@ typedef struct {
   int ld_in, ld_out; /* floats per activation row (>= c_in / c_out, multiple of 4) */
   int kernel, stride, padding, dilation;
   int transposed;    /* 0 = nn.Conv1d, 1 = nn.ConvTranspose1d; Linear: kernel=1,l=1 */
+  /* tuning overrides (results are bit-identical for every tile: the per-output summation
+   * order over K does not depend on it).  tile[kind] = BM*1000+BN with BM,BN in {64,128}, or
+   * 0 for the built-in heuristic; kind 0 fwd, 1 dgrad, 2 wgrad. */
+  int tile[3];
 } svae_conv_desc;
 
 /* y[b,lo,:] (+)= bias + sum_t x[b,li(lo,t),:] @ w[t]     (residual.py:79-109,137-170,

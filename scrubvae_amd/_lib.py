@@ -17,7 +17,7 @@ MAX_TAPS, MAX_JOINTS, MAX_CHAINS, MAX_CHAIN_LEN = 32, 32, 8, 8
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "batch", "l_in", "l_out", "c_in", "c_out", "ld_in", "ld_out",
-        "kernel", "stride", "padding", "dilation", "transposed")]
+        "kernel", "stride", "padding", "dilation", "transposed")] + [("tile", C.c_int * 3)]
 
 
 class Tree(C.Structure):

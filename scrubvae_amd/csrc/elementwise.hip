@@ -347,12 +347,20 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
   if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ part, int rows, int k, float scale, float* out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= k) return;
+// one 256-thread block per column: fp64 partials, fixed-shape tree => reproducible
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int rows, int k, float scale, float* out,
+                                                           int accumulate) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)part[(long long)r * k + c];
-  out[c] = (accumulate ? out[c] : 0.f) + (float)(s * (double)scale);
+  for (int r = threadIdx.x; r < rows; r += 256) s += (double)part[(long long)r * k + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)(red[0] * (double)scale);
 }
 
 // ------------------------------------------------------------------ small elementwise
@@ -580,7 +588,7 @@ extern "C" int svae_sumsq_partial(const float* x, long long n, float* part, void
 
 extern "C" int svae_reduce_rows(const float* part, int rows, int k, float scale, float* out, int accumulate, void* stream) {
   SVAE_REQUIRE(part && out && rows > 0 && k > 0, SVAE_ERR_ARG, "reduce_rows: bad args");
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((k + 127) / 128), dim3(128), 0, ST(stream), part, rows, k, scale, out, accumulate);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(k), dim3(256), 0, ST(stream), part, rows, k, scale, out, accumulate);
   return check_launch("reduce_rows");
 }
 

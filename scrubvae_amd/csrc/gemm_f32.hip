@@ -551,9 +551,17 @@ static Tile pick_tile(long long M0, long long M1, int N) {
   return best;
 }
 
+static bool decode_tile(int code, Tile& t) {
+  if (code <= 0) return false;
+  t.bm = code / 1000;
+  t.bn = code % 1000;
+  return (t.bm == 64 || t.bm == 128) && (t.bn == 64 || t.bn == 128);
+}
+
 template <bool B_KC>
-static int launch_gather_auto(GatherArgs& g, hipStream_t st) {
-  const Tile t = pick_tile(g.M[0], g.M[1], g.N);
+static int launch_gather_auto(GatherArgs& g, hipStream_t st, int override_code) {
+  Tile t;
+  if (!decode_tile(override_code, t)) t = pick_tile(g.M[0], g.M[1], g.N);
   for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + t.bm - 1) / t.bm);
   const int bm = g.blocks_m[0] + g.blocks_m[1];
   if (bm == 0) return SVAE_OK;
@@ -582,7 +590,7 @@ extern "C" int svae_conv_fwd(const svae_conv_desc* d, const float* x, const floa
   g.N = d->c_out;
   g.accumulate = accumulate;
   build_plan(g, d, /*strided=*/!d->transposed, d->l_out, d->l_in);
-  return launch_gather_auto<false>(g, (hipStream_t)stream);
+  return launch_gather_auto<false>(g, (hipStream_t)stream, d->tile[0]);
 }
 
 extern "C" int svae_conv_dgrad(const svae_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
@@ -599,7 +607,7 @@ extern "C" int svae_conv_dgrad(const svae_conv_desc* d, const float* dy, const f
   g.accumulate = accumulate;
   // conv: lo = (li + pad - t*dil)/stride (fractional); convT: lo = li*stride + t*dil - pad (strided)
   build_plan(g, d, /*strided=*/d->transposed != 0, d->l_in, d->l_out);
-  return launch_gather_auto<true>(g, (hipStream_t)stream);
+  return launch_gather_auto<true>(g, (hipStream_t)stream, d->tile[1]);
 }
 
 namespace svae {
@@ -615,7 +623,12 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
   w.bn = (w64 < w128) ? 64 : 128;
   w.ctiles = (d->c_in + w.bm - 1) / w.bm;
   long long tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
-  if (w.bm == 128 && w.bn == 128 && tiles < 256 && w.R < 16384) {  // few, short tiles: go finer
+  Tile ov;
+  if (decode_tile(d->tile[2], ov)) {
+    w.bm = ov.bm; w.bn = ov.bn;
+    w.ctiles = (d->c_in + w.bm - 1) / w.bm;
+    tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
+  } else if (w.bm == 128 && w.bn == 128 && tiles < 256 && w.R < 16384) {  // few, short tiles: go finer
     w.bm = 64;
     w.ctiles = (d->c_in + 63) / 64;
     tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
@@ -714,7 +727,8 @@ extern "C" int svae_conv_tile(const svae_conv_desc* d, int kind, int* bm, int* b
   memset(&g, 0, sizeof(g));
   if (kind == 0) { g.N = d->c_out; build_plan(g, d, !d->transposed, d->l_out, d->l_in); }
   else { g.N = d->c_in; build_plan(g, d, d->transposed != 0, d->l_in, d->l_out); }
-  const Tile t = pick_tile(g.M[0], g.M[1], g.N);
+  Tile t;
+  if (!decode_tile(d->tile[kind], t)) t = pick_tile(g.M[0], g.M[1], g.N);
   *bm = t.bm; *bn = t.bn;
   return SVAE_OK;
 }

@@ -56,6 +56,13 @@ class LaunchTimer:
 
 TIMER = None  # set to a LaunchTimer to enable
 
+# First-use tile autotuning of the GEMM launches (fwd/dgrad/wgrad): each (geometry, kind) times
+# the four workgroup tiles once on scratch outputs and keeps the fastest.  Results do not
+# depend on the tile (same per-output summation order), so this is numerically inert.
+AUTOTUNE = True
+AUTOTUNE_MIN_FLOPS = 2e8
+_TILES = (128128, 128064, 64128, 64064)
+
 
 _KIND_ID = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 
@@ -93,6 +100,35 @@ class Conv:
         # unpadded channel counts, L = output length (conv) / input length (transposed conv)
         self.flops = 2.0 * batch * (l_in if transposed else l_out) * kernel * c_in * c_out
 
+    def _tune(self, kind, run):
+        """run(): launches this conv once with scratch outputs.  Picks desc.tile[kind]."""
+        k = _KIND_ID[kind]
+        tuned = self.__dict__.setdefault("_tuned", set())
+        if kind in tuned:
+            return
+        tuned.add(kind)
+        if not AUTOTUNE or self.flops < AUTOTUNE_MIN_FLOPS or torch.cuda.is_current_stream_capturing():
+            return
+        best, best_t = 0, float("inf")
+        for code in _TILES:
+            self.desc.tile[k] = code
+            self._ws_bytes = None
+            try:
+                run()  # warm-up (also validates the workspace size for this tile)
+            except RuntimeError:
+                continue
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            run(); run()
+            e.record()
+            e.synchronize()
+            t = s.elapsed_time(e)
+            if t < best_t:
+                best, best_t = code, t
+        self.desc.tile[k] = best
+        self._ws_bytes = None
+        self.__dict__.pop("_names", None)
+
     def kernel_name(self, kind):
         """Name of the kernel template instance this call dispatches to (as rocprofv3 prints it)."""
         names = self.__dict__.setdefault("_names", {})
@@ -110,21 +146,52 @@ class Conv:
         return (self.kernel, self.c_in_p, self.c_out_p)
 
     def wgrad_workspace_bytes(self):
+        """Workspace for the current tile; before tuning: the maximum over all candidate tiles."""
+        if "wgrad" not in self.__dict__.get("_tuned", ()) and AUTOTUNE and self.flops >= AUTOTUNE_MIN_FLOPS:
+            keep, need = self.desc.tile[2], 0
+            for code in _TILES:
+                self.desc.tile[2] = code
+                need = max(need, int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc))))
+            self.desc.tile[2] = keep
+            return need
         if self._ws_bytes is None:
             self._ws_bytes = int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc)))
         return self._ws_bytes
 
     def fwd(self, x, w, bias, y, accumulate=False):
+        if "fwd" not in self.__dict__.get("_tuned", ()):
+            scratch = torch.empty(self.batch * self.l_out * self.desc.ld_out + 16, device=x.device)
+            self._tune("fwd", lambda: check(_lib.lib().svae_conv_fwd(
+                C.byref(self.desc), _p(x), _p(w), _p(bias), _p(scratch), 0, _stream()), "conv_fwd(tune)"))
         _timed("fwd", self, self.c_out_p, lambda: check(_lib.lib().svae_conv_fwd(
             C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), int(accumulate), _stream()), "conv_fwd"))
         return y
 
     def dgrad(self, dy, w, dx, accumulate=False):
+        if "dgrad" not in self.__dict__.get("_tuned", ()):
+            scratch = torch.empty(self.batch * self.l_in * self.desc.ld_in + 16, device=dy.device)
+            self._tune("dgrad", lambda: check(_lib.lib().svae_conv_dgrad(
+                C.byref(self.desc), _p(dy), _p(w), _p(scratch), 0, _stream()), "conv_dgrad(tune)"))
         _timed("dgrad", self, self.c_in_p, lambda: check(_lib.lib().svae_conv_dgrad(
             C.byref(self.desc), _p(dy), _p(w), _p(dx), int(accumulate), _stream()), "conv_dgrad"))
         return dx
 
     def wgrad(self, x, dy, dw, db, ws, accumulate=False):
+        if "wgrad" not in self.__dict__.get("_tuned", ()):
+            sdw = torch.empty(self.kernel * self.c_in_p * self.c_out_p + 16, device=x.device)
+            sdb = torch.empty(self.c_out_p, device=x.device)
+            self.desc.tile[2] = 0
+            need = 0
+            for code in _TILES:  # scratch workspace large enough for every candidate
+                self.desc.tile[2] = code
+                need = max(need, int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc))))
+            self.desc.tile[2] = 0
+            sws = torch.empty(need // 4 + 16, device=x.device)
+            self._tune("wgrad", lambda: check(_lib.lib().svae_conv_wgrad(
+                C.byref(self.desc), _p(x), _p(dy), _p(sdw), _p(sdb), _p(sws), sws.numel() * 4, 0, _stream()), "conv_wgrad(tune)"))
+            if ws.numel() * ws.element_size() < self.wgrad_workspace_bytes():
+                raise RuntimeError("conv_wgrad: workspace smaller than the tuned tile needs; size it with "
+                                   "Conv.wgrad_workspace_bytes() AFTER the first call or use ops.max_wgrad_workspace()")
         _timed("wgrad", self, self.c_out_p, lambda: check(_lib.lib().svae_conv_wgrad(
             C.byref(self.desc), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel() * ws.element_size(), int(accumulate),
             _stream()), "conv_wgrad"))

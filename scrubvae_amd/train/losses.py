@@ -56,6 +56,8 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     # ---- rotation (L4): seeds an extra gradient on x6d_hat that the tail adds
     ext_dx6d = None
     if "rotation" in loss_scale:
+        if not getattr(model, "_tail_done", True):  # deferred tail: the rotation loss reads x6d_hat
+            model._run_tail(B, dev_data, 0.0, 0.0, None, False)
         n = B * W * J
         part = model._buf("rot.part", (ops.rot_blocks(n),))
         x6d = model._prep(data["x6d"])
