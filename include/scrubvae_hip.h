@@ -102,6 +102,16 @@ int svae_bn_reduce_partials(const float* part, int n_chunks, int C, float* sums 
 int svae_bn_finalize(const float* sums, double count, int C, const float* gamma, const float* beta,
                      float eps, float momentum, float* running_mean, float* running_var,
                      float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* single-rank fast path: svae_bn_reduce_partials + svae_bn_finalize in one launch; also
+ * increments *num_batches_tracked (int64, may be NULL) */
+int svae_bn_stats_finalize(const float* part, int n_chunks, double count, int C, const float* gamma,
+                           const float* beta, float eps, float momentum, float* running_mean,
+                           float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                           float* scale, float* shift, void* stream);
+/* backward: chunk partials -> sums[2][C], plus (+)= dgamma, dbeta (from the sums) and dalpha
+ * (from dalpha_part[n_parts]); any of the three may be NULL */
+int svae_bn_bwd_reduce(const float* part, int n_chunks, int C, float* sums, float* dgamma, float* dbeta,
+                       float* dalpha, const float* dalpha_part, int n_parts, int accumulate, void* stream);
 /* eval mode: scale/shift from running stats */
 int svae_bn_eval_coeffs(int C, const float* gamma, const float* beta, float eps,
                         const float* running_mean, const float* running_var,
@@ -185,6 +195,18 @@ int svae_pose_tail(const float* y, int ld, const float* offsets, const float* ta
 int svae_rot_loss(const float* x6d, const float* x6d_hat, float scale, float* part, float* dx6d_hat,
                   long long n, void* stream);
 int svae_rot_blocks(long long n);
+
+/* Bias gradients of a whole step in two launches: out_t[c] (+)= sum over rows of x_t[:, c]. */
+#define SVAE_MAX_COLSUM_TASKS 48
+typedef struct {
+  const float* x; /* [rows, ld] */
+  float* out;     /* [C] */
+  long long rows;
+  int C, ld;
+} svae_colsum_task;
+size_t svae_colsum_batched_workspace(const svae_colsum_task* tasks, int n);
+int svae_colsum_batched(const svae_colsum_task* tasks, int n, void* ws, size_t ws_bytes, int accumulate,
+                        void* stream);
 
 /* ------------------------------------------------------------------------- optimizer --- */
 /* O1: torch.optim.AdamW / Adam step over one flat fp32 buffer (trainer.py:60-65,165).

@@ -20,6 +20,13 @@ class ConvDesc(C.Structure):
         "kernel", "stride", "padding", "dilation", "transposed")] + [("tile", C.c_int * 3)]
 
 
+class ColsumTask(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_longlong), ("C", C.c_int), ("ld", C.c_int)]
+
+
+MAX_COLSUM_TASKS = 48
+
+
 class Tree(C.Structure):
     _fields_ = [("n_joints", C.c_int), ("n_chains", C.c_int),
                 ("chain_len", C.c_int * MAX_CHAINS),
@@ -58,6 +65,10 @@ SIGNATURES = {
     "svae_bn_stats_partial": (I, [P, LL, I, I, P, P]),
     "svae_bn_reduce_partials": (I, [P, I, I, P, P]),
     "svae_bn_finalize": (I, [P, D, I, P, P, F, F, P, P, P, P, P, P, P]),
+    "svae_bn_stats_finalize": (I, [P, I, D, I, P, P, F, F, P, P, P, P, P, P, P, P]),
+    "svae_bn_bwd_reduce": (I, [P, I, I, P, P, P, P, P, I, I, P]),
+    "svae_colsum_batched_workspace": (SZ, [C.POINTER(ColsumTask), I]),
+    "svae_colsum_batched": (I, [C.POINTER(ColsumTask), I, P, SZ, I, P]),
     "svae_bn_eval_coeffs": (I, [I, P, P, F, P, P, P, P, P]),
     "svae_affine_prelu_fwd": (I, [P, P, P, P, P, LL, I, I, P]),
     "svae_affine_prelu_bwd_partial": (I, [P, P, P, P, P, P, P, LL, I, I, P, P, P]),

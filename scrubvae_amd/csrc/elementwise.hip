@@ -99,6 +99,58 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, double count,
   }
 }
 
+// reduce the chunk partials AND finalize in one launch (single-rank path: no all-reduce between)
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, double count, int C,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                         float* running_mean, float* running_var, long long* num_batches_tracked, float* mean_o,
+                                         float* rstd_o, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int ch = 0; ch < chunks; ++ch) {
+    s0 += (double)part[((long long)ch * 2) * C + c];
+    s1 += (double)part[((long long)ch * 2 + 1) * C + c];
+  }
+  const double mean = s0 / count;
+  double var = s1 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma[c], b = beta[c];
+  mean_o[c] = (float)mean;
+  rstd_o[c] = rstd;
+  scale[c] = g * rstd;
+  shift[c] = b - (float)mean * g * rstd;
+  if (running_mean != nullptr) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+// backward: reduce the chunk partials to sums[2][C] and emit the parameter gradients
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ sums, float* dgamma,
+                                     float* dbeta, float* dalpha, const float* __restrict__ dalpha_part, int n_parts,
+                                     int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int ch = 0; ch < chunks; ++ch) {
+      s0 += (double)part[((long long)ch * 2) * C + c];
+      s1 += (double)part[((long long)ch * 2 + 1) * C + c];
+    }
+    sums[c] = (float)s0;
+    sums[C + c] = (float)s1;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s0;
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s1;
+  }
+  if (c == 0 && dalpha != nullptr) {
+    double s = 0.0;
+    for (int i = 0; i < n_parts; ++i) s += (double)dalpha_part[i];
+    dalpha[0] = (accumulate ? dalpha[0] : 0.f) + (float)s;
+  }
+}
+
 __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float* scale, float* shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,6 +317,66 @@ __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restr
     }
     st4(dx + row * ld + c, r);
   }
+}
+
+// ---------------------------------------------------------------- batched column sums
+// bias gradients of every conv/linear of a step in two launches: task t sums the rows of its
+// dY matrix per column.  part layout: task -> [chunks_t][C_t] starting at part_off[t].
+constexpr int CS_ROWS = 512;
+struct ColsumTasks {
+  const float* x[SVAE_MAX_COLSUM_TASKS];
+  float* out[SVAE_MAX_COLSUM_TASKS];
+  long long rows[SVAE_MAX_COLSUM_TASKS];
+  long long part_off[SVAE_MAX_COLSUM_TASKS];
+  int C[SVAE_MAX_COLSUM_TASKS], ld[SVAE_MAX_COLSUM_TASKS];
+  int blk_begin[SVAE_MAX_COLSUM_TASKS + 1];  // first block id of each task (stage 1)
+  int col_begin[SVAE_MAX_COLSUM_TASKS + 1];  // first global column of each task (stage 2)
+  int n;
+};
+
+__global__ __launch_bounds__(256) void colsum_batched_partial_kernel(const ColsumTasks T, float* __restrict__ part) {
+  __shared__ float red[16][65];
+  int t = 0;
+  while (t + 1 < T.n && (int)blockIdx.x >= T.blk_begin[t + 1]) ++t;
+  const int local = blockIdx.x - T.blk_begin[t];
+  const int C = T.C[t], ld = T.ld[t];
+  const int colblocks = (C + 63) / 64;
+  const int chunk = local / colblocks, cb = local - chunk * colblocks;
+  const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = cb * 64 + c4 * 4;
+  const long long r0 = (long long)chunk * CS_ROWS;
+  long long r1 = r0 + CS_ROWS;
+  if (r1 > T.rows[t]) r1 = T.rows[t];
+  const float* x = T.x[t];
+  float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C)
+    for (long long r = r0 + rl; r < r1; r += 16) {
+      const float4 v = ld4(x + r * ld + c);
+      sv.x += v.x; sv.y += v.y; sv.z += v.z; sv.w += v.w;
+    }
+  red[rl][c4 * 4 + 0] = sv.x; red[rl][c4 * 4 + 1] = sv.y; red[rl][c4 * 4 + 2] = sv.z; red[rl][c4 * 4 + 3] = sv.w;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float tt = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tt += red[i][threadIdx.x];
+    const int cc = cb * 64 + threadIdx.x;
+    if (cc < C) part[T.part_off[t] + (long long)chunk * C + cc] = tt;
+  }
+}
+
+__global__ void colsum_batched_final_kernel(const ColsumTasks T, const float* __restrict__ part, int accumulate) {
+  const int gc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gc >= T.col_begin[T.n]) return;
+  int t = 0;
+  while (t + 1 < T.n && gc >= T.col_begin[t + 1]) ++t;
+  const int c = gc - T.col_begin[t];
+  const int C = T.C[t];
+  const int chunks = (int)((T.rows[t] + CS_ROWS - 1) / CS_ROWS);
+  double s = 0.0;
+  for (int k = 0; k < chunks; ++k) s += (double)part[T.part_off[t] + (long long)k * C + c];
+  float* o = T.out[t];
+  o[c] = (accumulate ? o[c] : 0.f) + (float)s;
 }
 
 // ------------------------------------------------------------------------ latent heads
@@ -635,4 +747,59 @@ extern "C" int svae_double_softmax_ce_sum(const float* logits, int ld, int rows,
   hipLaunchKernelGGL(double_softmax_ce_kernel, dim3(svae_rowloss_blocks(rows)), dim3(256), 0, ST(stream), logits, ld, rows, scale,
                      part, dlogits);
   return check_launch("double_softmax_ce_sum");
+}
+
+extern "C" int svae_bn_stats_finalize(const float* part, int n_chunks, double count, int C, const float* gamma,
+                                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                      long long* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift,
+                                      void* stream) {
+  SVAE_REQUIRE(part && gamma && beta && mean && rstd && scale && shift && count > 0 && n_chunks > 0, SVAE_ERR_ARG,
+               "bn_stats_finalize: bad args");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), part, n_chunks, count, C, gamma,
+                     beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale, shift);
+  return check_launch("bn_stats_finalize");
+}
+
+extern "C" int svae_bn_bwd_reduce(const float* part, int n_chunks, int C, float* sums, float* dgamma, float* dbeta,
+                                  float* dalpha, const float* dalpha_part, int n_parts, int accumulate, void* stream) {
+  SVAE_REQUIRE(part && sums && n_chunks > 0 && (!dalpha || dalpha_part), SVAE_ERR_ARG, "bn_bwd_reduce: bad args");
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), part, n_chunks, C, sums, dgamma, dbeta,
+                     dalpha, dalpha_part, n_parts, accumulate);
+  return check_launch("bn_bwd_reduce");
+}
+
+extern "C" size_t svae_colsum_batched_workspace(const svae_colsum_task* tasks, int n) {
+  if (!tasks || n <= 0 || n > SVAE_MAX_COLSUM_TASKS) return 0;
+  size_t f = 0;
+  for (int t = 0; t < n; ++t) f += (size_t)((tasks[t].rows + CS_ROWS - 1) / CS_ROWS) * tasks[t].C;
+  return f * sizeof(float) + 256;
+}
+
+extern "C" int svae_colsum_batched(const svae_colsum_task* tasks, int n, void* ws, size_t ws_bytes, int accumulate,
+                                   void* stream) {
+  SVAE_REQUIRE(tasks && n > 0 && n <= SVAE_MAX_COLSUM_TASKS && ws, SVAE_ERR_ARG, "colsum_batched: bad args (n=%d)", n);
+  SVAE_REQUIRE(ws_bytes >= svae_colsum_batched_workspace(tasks, n), SVAE_ERR_WORKSPACE, "colsum_batched: workspace too small");
+  ColsumTasks T;
+  memset(&T, 0, sizeof(T));
+  T.n = n;
+  long long off = 0;
+  int blk = 0, col = 0;
+  for (int t = 0; t < n; ++t) {
+    SVAE_REQUIRE(tasks[t].x && tasks[t].out && tasks[t].rows > 0 && tasks[t].C > 0 && tasks[t].C % 4 == 0 && tasks[t].ld % 4 == 0,
+                 SVAE_ERR_ARG, "colsum_batched: bad task %d", t);
+    T.x[t] = tasks[t].x; T.out[t] = tasks[t].out; T.rows[t] = tasks[t].rows; T.C[t] = tasks[t].C; T.ld[t] = tasks[t].ld;
+    const int chunks = (int)((tasks[t].rows + CS_ROWS - 1) / CS_ROWS);
+    T.part_off[t] = off;
+    off += (long long)chunks * tasks[t].C;
+    T.blk_begin[t] = blk;
+    blk += chunks * ((tasks[t].C + 63) / 64);
+    T.col_begin[t] = col;
+    col += tasks[t].C;
+  }
+  T.blk_begin[n] = blk;
+  T.col_begin[n] = col;
+  hipLaunchKernelGGL(colsum_batched_partial_kernel, dim3(blk), dim3(256), 0, ST(stream), T, (float*)ws);
+  if (int e = check_launch("colsum_batched_partial")) return e;
+  hipLaunchKernelGGL(colsum_batched_final_kernel, dim3((col + 127) / 128), dim3(128), 0, ST(stream), T, (const float*)ws, accumulate);
+  return check_launch("colsum_batched_final");
 }

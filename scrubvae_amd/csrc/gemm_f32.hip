@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
   const int nk = ntaps * tiles_per_tap;
 
   float4 ra[APASS], rb[BPASS];
+  bool ra_ok[APASS], rb_ok[BPASS];  // zero-fill is applied when the tile is written to LDS
   // tap bookkeeping is advanced incrementally and one tile AHEAD of its use, so that the
   // scalar loads of the tap table never sit in front of the global loads / MFMAs
   int nx_c0 = 0, nx_ti = 0;
@@ -126,49 +127,51 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
         nx_woff = (long long)tap_w[nx_ti] * g.w_tap_stride;
       }
     }
+    // branch-free: clamped address + select, so the whole K-tile body is ONE basic block and
+    // the scheduler can slide these loads between the MFMAs
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const int li = a_j[i] + tb;
-      if (li >= 0 && li < g.Lin)
-        ra[i] = ld4(g.A + a_off[i] + (long long)li * g.ldA + c0);
-      else
-        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = li >= 0 && li < g.Lin;
+      const int lic = ok ? li : 0;
+      ra[i] = ld4(g.A + a_off[i] + (long long)lic * g.ldA + c0);
+      ra_ok[i] = ok;
     }
     if constexpr (B_KC) {
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
         const int n = n0 + (tid >> 2) + 64 * i;
-        if (n < g.N)
-          rb[i] = ld4(wt + (long long)n * g.ldW + c0 + akq * 4);
-        else
-          rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ok = n < g.N;
+        rb[i] = ld4(wt + (long long)(ok ? n : 0) * g.ldW + c0 + akq * 4);
+        rb_ok[i] = ok;
       }
     } else {
       constexpr int F4_PER_ROW = BN / 4;
       constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
       const int n = n0 + (tid % F4_PER_ROW) * 4;
+      const bool ok = n < g.N;
+      const int nc = ok ? n : 0;
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
         const int k = tid / F4_PER_ROW + ROWS_PER_PASS * i;
-        if (n < g.N)
-          rb[i] = ld4(wt + (long long)(c0 + k) * g.ldW + n);
-        else
-          rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[i] = ld4(wt + (long long)(c0 + k) * g.ldW + nc);
+        rb_ok[i] = ok;
       }
     }
   };
   auto store_tile = [&](int buf) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < APASS; ++i) st4(&As[buf][((tid >> 2) + 64 * i) * LDK + akq * 4], ra[i]);
+    for (int i = 0; i < APASS; ++i) st4(&As[buf][((tid >> 2) + 64 * i) * LDK + akq * 4], ra_ok[i] ? ra[i] : zero4);
     if constexpr (B_KC) {
 #pragma unroll
-      for (int i = 0; i < BPASS; ++i) st4(&Bs[buf][((tid >> 2) + 64 * i) * LDK + akq * 4], rb[i]);
+      for (int i = 0; i < BPASS; ++i) st4(&Bs[buf][((tid >> 2) + 64 * i) * LDK + akq * 4], rb_ok[i] ? rb[i] : zero4);
     } else {
       constexpr int F4_PER_ROW = BN / 4;
       constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
 #pragma unroll
       for (int i = 0; i < BPASS; ++i)
-        st4(&Bs[buf][(tid / F4_PER_ROW + ROWS_PER_PASS * i) * BN + (tid % F4_PER_ROW) * 4], rb[i]);
+        st4(&Bs[buf][(tid / F4_PER_ROW + ROWS_PER_PASS * i) * BN + (tid % F4_PER_ROW) * 4], rb_ok[i] ? rb[i] : zero4);
     }
   };
 
@@ -192,11 +195,11 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile();
     const float* as = As[buf];
     const float* bs = Bs[buf];
-    // all LDS fragment reads of the K tile are issued up front (32 VGPRs); the MFMAs then
-    // start as soon as the first fragments land and the rest arrive under them
+    // all LDS fragment reads of the K tile are issued up front (32 VGPRs); the MFMAs start as
+    // soon as the first fragments land.  The global loads (+ address maths) of the NEXT tile sit
+    // between the two MFMA halves, where the matrix pipe is busy for ~1000 cycles anyway.
     float4 av[2][MT], bv[2][NT];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -226,6 +229,11 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
           }
         }
+      }
+      if (q == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) load_tile();
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (kt + 1 < nk) store_tile(buf ^ 1);

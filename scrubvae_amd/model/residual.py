@@ -186,6 +186,7 @@ class ResVAE(nn.Module):
         self._convs = {}
         self._runners = {}
         self._pending = None
+        self._db_batch = ops.ColsumBatch()
         self._tree = make_tree(self.n_keypts, kinematic_tree) if kinematic_tree is not None else None
         self._arena_host = None if arena_size is None else [float(v) for v in torch.as_tensor(arena_size).flatten()]
         self._materialise(torch.device(device))
@@ -290,6 +291,20 @@ class ResVAE(nn.Module):
             self._ws["wgrad_ws"] = t
         return t
 
+    def _wgrad(self, cv, x, dy, p, acc):
+        """Weight gradient now; the bias gradient (column sums of dy) is queued and reduced with
+        all the others in two launches at the end of the reverse schedule."""
+        cv.wgrad(x, dy, p.weight.grad, None, self._wgrad_ws(cv), accumulate=acc)
+        self._db_batch.add(dy, cv.batch * cv.l_out, cv.c_out_p, cv.desc.ld_out, p.bias.grad)
+
+    def _colsum_ws(self, nbytes):
+        n = nbytes // 4 + 16
+        t = self._ws.get("colsum_ws")
+        if t is None or t.numel() < n:
+            t = torch.empty(n, device=self.device)
+            self._ws["colsum_ws"] = t
+        return t
+
     def _allreduce(self, t):
         if self.world_size > 1:
             import torch.distributed as dist
@@ -311,14 +326,15 @@ class ResVAE(nn.Module):
             sums = self._buf(tag + ".sums", (2, Cp))
             mean, rstd = self._buf(tag + ".mean", (Cp,)), self._buf(tag + ".rstd", (Cp,))
             ops.bn_stats_partial(x, rows, Cp, Cp, part)
-            ops.bn_reduce_partials(part, nch, Cp, sums)
-            count = rows
             if self.world_size > 1 and self.sync_bn:
+                ops.bn_reduce_partials(part, nch, Cp, sums)
                 self._allreduce(sums)
-                count = rows * self.world_size
-            ops.bn_finalize(sums, count, Cp, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                            mean, rstd, scale, shift)
-            bn.num_batches_tracked.add_(1)
+                ops.bn_finalize(sums, rows * self.world_size, Cp, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
+                                bn.running_var, mean, rstd, scale, shift)
+                bn.num_batches_tracked.add_(1)
+            else:  # one launch: chunk reduction + finalize + running stats + num_batches_tracked
+                ops.bn_stats_finalize(part, nch, rows, Cp, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
+                                      bn.running_var, bn.num_batches_tracked, mean, rstd, scale, shift)
         else:
             ops.bn_eval_coeffs(Cp, bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, scale, shift)
         ops.affine_prelu_fwd(x, scale, shift, act.weight, out, rows, Cp, Cp)
@@ -333,9 +349,9 @@ class ResVAE(nn.Module):
         mean, rstd = self._buf(tag + ".mean", (Cp,)), self._buf(tag + ".rstd", (Cp,))
         sums = self._buf(tag + ".dsums", (2, Cp))
         ops.affine_prelu_bwd_partial(dy, x, scale, shift, mean, rstd, act.weight, rows, Cp, Cp, part, dap)
-        ops.bn_reduce_partials(part, nch, Cp, sums)
         count = rows
         if self.world_size > 1 and self.sync_bn:
+            ops.bn_reduce_partials(part, nch, Cp, sums)
             # parameter grads come from the LOCAL sums (the gradient all-reduce sums them
             # later); the input gradient needs the global ones
             gl = self._buf(tag + ".dsums_g", (2, Cp))
@@ -350,8 +366,9 @@ class ResVAE(nn.Module):
                 bn.bias.grad.copy_(sums[0])
                 bn.weight.grad.copy_(sums[1])
         else:
+            ops.bn_bwd_reduce(part, nch, Cp, sums, bn.weight.grad, bn.bias.grad, act.weight.grad, dap, dap.numel(), acc)
             ops.affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, bn.weight, act.weight, sums, count, dx, rows, Cp, Cp,
-                                       bn.weight.grad, bn.bias.grad, act.weight.grad, dap, nch, acc)
+                                       None, None, None, dap, nch, acc)
         return dx
 
     # ------------------------------------------------------------------ forward pieces
@@ -608,7 +625,7 @@ class ResVAE(nn.Module):
             lens.append((lens[-1] - 1) * 2 - 2 * (self.kernel // 2) + (self.kernel - 1) + 1)
         d_in_last = self._buf(f"dec.{len(dec.res_layers) - 1}.a", (B * lens[-1], pad16(ch[0])))
         cvo = self._conv("dec.out", dec.conv_out, B, lens[-1])
-        cvo.wgrad(d_in_last, dy, dec.conv_out.weight.grad, dec.conv_out.bias.grad, self._wgrad_ws(cvo), accumulate=acc)
+        self._wgrad(cvo, d_in_last, dy, dec.conv_out, acc)
         g = self._buf("g.dec.top", (B * lens[-1], pad16(ch[0])))
         cvo.dgrad(dy, dec.conv_out.weight, g)
         for j in range(len(dec.res_layers) - 1, -1, -1):
@@ -626,8 +643,8 @@ class ResVAE(nn.Module):
             self._bn_act_bwd(t + ".bn2", g, s, blk.add[0], blk.add[1], B * Lo, g_s, acc)
             up = self._buf(t + ".up", (B * 2 * L, cv1.c_in_p))
             t0a = self._buf(t + ".t0a", (B * L, cv1.c_out_p))
-            cvs.wgrad(up, g_s, sk.weight.grad, sk.bias.grad, self._wgrad_ws(cvs), accumulate=acc)
-            cv2.wgrad(t0a, g_s, ct2.weight.grad, ct2.bias.grad, self._wgrad_ws(cv2), accumulate=acc)
+            self._wgrad(cvs, up, g_s, sk, acc)
+            self._wgrad(cv2, t0a, g_s, ct2, acc)
             g_up = self._buf("g." + t + ".up", (B * 2 * L, cv1.c_in_p))
             cvs.dgrad(g_s, sk.weight, g_up)
             g_d = self._buf("g." + t + ".in", (B * L, cv1.c_in_p))
@@ -637,7 +654,7 @@ class ResVAE(nn.Module):
             t0 = self._buf(t + ".t0", (B * L, cv1.c_out_p))
             g_t0 = self._buf("g." + t + ".t0", (B * L, cv1.c_out_p))
             self._bn_act_bwd(t + ".bn1", g_t0a, t0, bn1, act1, B * L, g_t0, acc)
-            cv1.wgrad(d_in, g_t0, ct1.weight.grad, ct1.bias.grad, self._wgrad_ws(cv1), accumulate=acc)
+            self._wgrad(cv1, d_in, g_t0, ct1, acc)
             cv1.dgrad(g_t0, ct1.weight, g_d, accumulate=True)
             g = g_d
         # ---- fc_in
@@ -645,7 +662,7 @@ class ResVAE(nn.Module):
         zcp = zc.shape[1]
         lin = self._lin("fc_in", dec.fc_in, B)
         g_f = g.view(B, -1)
-        lin.wgrad(zc, g_f, dec.fc_in.weight.grad, dec.fc_in.bias.grad, self._wgrad_ws(lin), accumulate=acc)
+        self._wgrad(lin, zc, g_f, dec.fc_in, acc)
         g_zc = self._buf("g.zc", (B, zcp))
         lin.dgrad(g_f, dec.fc_in.weight, g_zc)
         # ---- heads: dh = [dmu | draw]
@@ -657,8 +674,8 @@ class ResVAE(nn.Module):
         fm, fs = enc.fc_mu, enc.fc_sigma[0]
         lm = self._lin("fc_mu", fm, B, ld_out=2 * zp)
         ls = self._lin("fc_sigma", fs, B, ld_out=2 * zp)
-        lm.wgrad(flat, dh, fm.weight.grad, fm.bias.grad, self._wgrad_ws(lm), accumulate=acc)
-        ls.wgrad(flat, dh[:, zp:], fs.weight.grad, fs.bias.grad, self._wgrad_ws(ls), accumulate=acc)
+        self._wgrad(lm, flat, dh, fm, acc)
+        self._wgrad(ls, flat, dh[:, zp:], fs, acc)
         g_flat = self._buf("g.flat", tuple(flat.shape))
         lm.dgrad(dh, fm.weight, g_flat)
         ls.dgrad(dh[:, zp:], fs.weight, g_flat, accumulate=True)
@@ -680,14 +697,14 @@ class ResVAE(nn.Module):
             g_s = self._buf("g." + t + ".s", (B * Lo, cv3.c_out_p))
             self._bn_act_bwd(t + ".bn2", g, s, blk.add[0], blk.add[1], B * Lo, g_s, acc)
             r0a = self._buf(t + ".r0a", (B * Lo, cv0.c_out_p))
-            cvs.wgrad(a_in, g_s, blk.skip.weight.grad, blk.skip.bias.grad, self._wgrad_ws(cvs), accumulate=acc)
-            cv3.wgrad(r0a, g_s, conv3.weight.grad, conv3.bias.grad, self._wgrad_ws(cv3), accumulate=acc)
+            self._wgrad(cvs, a_in, g_s, blk.skip, acc)
+            self._wgrad(cv3, r0a, g_s, conv3, acc)
             g_r0a = self._buf("g." + t + ".r0a", (B * Lo, cv0.c_out_p))
             cv3.dgrad(g_s, conv3.weight, g_r0a)
             r0 = self._buf(t + ".r0", (B * Lo, cv0.c_out_p))
             g_r0 = self._buf("g." + t + ".r0", (B * Lo, cv0.c_out_p))
             self._bn_act_bwd(t + ".bn1", g_r0a, r0, bn1, act1, B * Lo, g_r0, acc)
-            cv0.wgrad(a_in, g_r0, conv0.weight.grad, conv0.bias.grad, self._wgrad_ws(cv0), accumulate=acc)
+            self._wgrad(cv0, a_in, g_r0, conv0, acc)
             g_a = self._buf("g." + t + ".in", (B * L, cv0.c_in_p))
             cvs.dgrad(g_s, blk.skip.weight, g_a)
             cv0.dgrad(g_r0, conv0.weight, g_a, accumulate=True)
@@ -704,7 +721,8 @@ class ResVAE(nn.Module):
                                    None, None, enc.activation.weight.grad, dap, nch, acc)
         x_in = self._buf("x_in", (rows, pad16(self.in_channels)))
         cvi = self._conv("enc.conv_in", enc.conv_in, B, W)
-        cvi.wgrad(x_in, g_c0, enc.conv_in.weight.grad, enc.conv_in.bias.grad, self._wgrad_ws(cvi), accumulate=acc)
+        self._wgrad(cvi, x_in, g_c0, enc.conv_in, acc)
+        self._db_batch.flush(self._colsum_ws, accumulate=acc)
         # ---- data-parallel: sum gradients over ranks (losses are normalised by the GLOBAL batch)
         if self.world_size > 1:
             self._allreduce(self.flat_grads)

@@ -117,13 +117,15 @@ class Conv:
                 run()  # warm-up (also validates the workspace size for this tile)
             except RuntimeError:
                 continue
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            run(); run()
-            e.record()
-            e.synchronize()
-            t = s.elapsed_time(e)
-            if t < best_t:
+            t = float("inf")
+            for _ in range(4):  # min of 4 single-launch timings: robust against one-off stalls
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                run()
+                e.record()
+                e.synchronize()
+                t = min(t, s.elapsed_time(e))
+            if t < best_t * 0.98:  # candidates are ordered large -> small: ties keep the larger tile
                 best, best_t = code, t
         self.desc.tile[k] = best
         self._ws_bytes = None
@@ -271,6 +273,39 @@ def bn_reduce_partials(part, n_chunks, Cp, sums):
 def bn_finalize(sums, count, Cp, gamma, beta, eps, momentum, rmean, rvar, mean, rstd, scale, shift):
     check(_lib.lib().svae_bn_finalize(_p(sums), float(count), Cp, _p(gamma), _p(beta), eps, momentum, _p(rmean), _p(rvar),
                                       _p(mean), _p(rstd), _p(scale), _p(shift), _stream()), "bn_finalize")
+
+
+def bn_stats_finalize(part, n_chunks, count, Cp, gamma, beta, eps, momentum, rmean, rvar, nbt, mean, rstd, scale, shift):
+    check(_lib.lib().svae_bn_stats_finalize(_p(part), n_chunks, float(count), Cp, _p(gamma), _p(beta), eps, momentum, _p(rmean),
+                                            _p(rvar), _p(nbt), _p(mean), _p(rstd), _p(scale), _p(shift), _stream()), "bn_stats_finalize")
+
+
+def bn_bwd_reduce(part, n_chunks, Cp, sums, dgamma, dbeta, dalpha, dalpha_part, n_parts, accumulate):
+    check(_lib.lib().svae_bn_bwd_reduce(_p(part), n_chunks, Cp, _p(sums), _p(dgamma), _p(dbeta), _p(dalpha), _p(dalpha_part),
+                                        n_parts, int(accumulate), _stream()), "bn_bwd_reduce")
+
+
+class ColsumBatch:
+    """Collects (dY, bias.grad) pairs during the backward schedule and reduces them all in two
+    launches (svae_colsum_batched)."""
+
+    def __init__(self):
+        self.tasks = []
+
+    def add(self, x, rows, Cp, ld, out):
+        self.tasks.append((x, rows, Cp, ld, out))
+
+    def flush(self, get_ws, accumulate=False):
+        for i in range(0, len(self.tasks), _lib.MAX_COLSUM_TASKS):
+            chunk = self.tasks[i: i + _lib.MAX_COLSUM_TASKS]
+            arr = (_lib.ColsumTask * len(chunk))()
+            for t, (x, rows, Cp, ld, out) in zip(arr, chunk):
+                t.x, t.out, t.rows, t.C, t.ld = x.data_ptr(), out.data_ptr(), rows, Cp, ld
+            need = int(_lib.lib().svae_colsum_batched_workspace(arr, len(chunk)))
+            ws = get_ws(need)
+            check(_lib.lib().svae_colsum_batched(arr, len(chunk), _p(ws), ws.numel() * ws.element_size(), int(accumulate),
+                                                 _stream()), "colsum_batched")
+        self.tasks = []
 
 
 def bn_eval_coeffs(Cp, gamma, beta, eps, rmean, rvar, scale, shift):
