@@ -96,6 +96,22 @@ def cpu_baseline(args, method, feats, loss, sample_b=128, steps=3):
             "sample": f"{steps} optimizer steps of the CPU oracle at batch {sample_b} (same model/loss config), {dt*1e3:.0f} ms/step"}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 corrections applied by
+    tools/summarize_pmc.py); None when no summary for this kernel is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        return None if not k or not k.get("hbm_bytes_per_launch") else {
+            "hbm_bytes_per_launch": round(k["hbm_bytes_per_launch"]), "source": os.path.basename(files[-1])}
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     from scrubvae_amd import parallel, ops
@@ -132,7 +148,15 @@ def main():
         step()
     timer = None
     if not args.no_roofline:
-        timer = ops.LaunchTimer(kinds=tuple(args.timer_kinds.split(",")))
+        # one probe step brackets every forward/data-gradient GEMM launch to find the dominant
+        # kernel template; the timed region then brackets only that template's launches
+        probe = ops.LaunchTimer(kinds=tuple(args.timer_kinds.split(",")))
+        ops.TIMER = probe
+        step()
+        ops.TIMER = None
+        summ = probe.summary()
+        dominant = max(summ.items(), key=lambda kv: kv[1]["ms"])[0]
+        timer = ops.LaunchTimer(kinds=tuple(args.timer_kinds.split(",")), only=dominant)
         ops.TIMER = timer
     barrier()
     t0 = time.perf_counter()
@@ -168,14 +192,15 @@ def main():
                 kname, s = max(summ.items(), key=lambda kv: kv[1]["ms"])
                 tf = s["flops"] / (s["ms"] * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": "svae::" + kname,
+                                   "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("svae::" + kname),
+                                   "kernel": "svae::" + kname,
                                    "launches_per_step": s["launches"] // args.steps,
                                    "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2),
                                    "avg_launch_gflop": round(s["flops"] / s["launches"] / 1e9, 3),
-                                   "all_timed_kernels": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                                             "avg_us": round(v["ms"] * 1e3 / v["launches"], 2),
-                                                             "launches_per_step": v["launches"] // args.steps}
-                                                         for k, v in sorted(summ.items())}}
+                                   "probe_step_all_gemm_templates": {
+                                       k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                           "avg_us": round(v["ms"] * 1e3 / v["launches"], 2), "launches_per_step": v["launches"]}
+                                       for k, v in sorted(probe.summary().items())}}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, method, feats, loss)
         print(json.dumps(out), flush=True)

@@ -38,8 +38,9 @@ class LaunchTimer:
     launched on.  kinds: subset of {"fwd", "dgrad", "wgrad"}; only launches whose kernel
     template matches `bn` (64/128, None = any) are bracketed."""
 
-    def __init__(self, kinds=("fwd",)):
+    def __init__(self, kinds=("fwd",), only=None):
         self.kinds = set(kinds)
+        self.only = only  # restrict to one kernel template name (keeps the event overhead small)
         self.records = []  # (kernel template name, flops, start_event, end_event)
 
     def summary(self):
@@ -69,7 +70,7 @@ _KIND_ID = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 
 def _timed(kind, conv, n_padded, fn):
     t = TIMER
-    if t is None or kind not in t.kinds:
+    if t is None or kind not in t.kinds or (t.only is not None and conv.kernel_name(kind) != t.only):
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
