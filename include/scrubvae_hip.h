@@ -157,6 +157,16 @@ int svae_heads_diag_bwd(const float* h, int ld, const float* eps, const float* s
                         const float* dz, int lddz, const float* dmu, const float* dsigma, float kl_scale,
                         float* dh, int batch, int zdim, int raw_off, int ldm, void* stream);
 
+/* Full-Cholesky variant (model.diag = False; CholeskyL residual.py:39-68): raw holds the
+ * z(z+1)/2 lower-triangle entries in torch.tril_indices order at h[:, raw_off:], softplus on
+ * the diagonal; L [B,z,z] is written densely (zeros above the diagonal); z = L eps + mu;
+ * kl_part as above with diag(L L^T) = row sums of squares. */
+int svae_heads_tril_fwd(const float* h, int ld, const float* eps, float* mu, int ldm, float* L, float* z,
+                        int ldz, float* kl_part, int batch, int zdim, int raw_off, void* stream);
+int svae_heads_tril_bwd(const float* h, int ld, const float* eps, const float* L, const float* dz, int lddz,
+                        const float* dmu, int ldm, float kl_scale, float* dh, int batch, int zdim,
+                        int raw_off, void* stream);
+
 /* ----------------------------------------------------------------- pose-loss tail --- */
 typedef struct {
   int n_joints;

@@ -164,8 +164,8 @@ class ResVAE(nn.Module):
         self.conditional_keys = conditional_keys
         self.discrete_classes = discrete_classes
         self.n_keypts = (in_channels - (3 if arena_size is not None else 0)) // 6
-        if not is_diag:
-            raise NotImplementedError("full-Cholesky latent (model.diag=False) is not implemented on the HIP path yet")
+        self.sig_dim = z_dim if is_diag else z_dim * (z_dim + 1) // 2
+        self._hw = pad16(z_dim) + pad16(self.sig_dim)  # row width of the [mu | raw] head buffer
         self.encoder = ResidualEncoder(in_channels, ch, kernel, z_dim, window, activation, is_diag, prior, init_dilation)
         self.decoder = ResidualDecoder(in_channels, ch, kernel, z_dim, window, activation, conditional_dim, init_dilation)
         if self.encoder.latent_len < 1:
@@ -215,6 +215,10 @@ class ResVAE(nn.Module):
             p = nn.Parameter(self.flat_params[off: off + numel].view(shape), requires_grad=id(m) not in frozen)
             m.register_parameter(pname, p)
             self._slots.append((p, off, numel, shape))
+        # contiguous span of the decoder's parameters in the flat buffers (first all-reduce bucket)
+        dec_ids = {id(m) for m in self.decoder.modules()}
+        dec = [(off, off + (numel + 3) // 4 * 4) for m, pname, shape, off, numel in slots if id(m) in dec_ids]
+        self._dec_span = (min(a for a, _ in dec), max(b for _, b in dec))
         self.to(device)  # buffers
         self._assign_grad_views()
 
@@ -305,7 +309,9 @@ class ResVAE(nn.Module):
             self._ws["colsum_ws"] = t
         return t
 
-    def _allreduce(self, t):
+    def _allreduce(self, t, async_op=False):
+        """SUM all-reduce over the data-parallel group.  async_op: returns a work handle (RCCL
+        runs it on its own stream after the kernels already queued on the current stream)."""
         if self.world_size > 1:
             import torch.distributed as dist
             if t.is_cuda and dist.get_backend(self.process_group) == "gloo":
@@ -313,8 +319,9 @@ class ResVAE(nn.Module):
                 h = t.detach().cpu()
                 dist.all_reduce(h, group=self.process_group)
                 t.copy_(h)
-            else:
-                dist.all_reduce(t, group=self.process_group)
+                return None
+            return dist.all_reduce(t, group=self.process_group, async_op=async_op)
+        return None
 
     # ------------------------------------------------------------------ BN + PReLU stage
     def _bn_act(self, tag, x, bn: BatchNormP, act: PReLUP, rows, out):
@@ -424,10 +431,10 @@ class ResVAE(nn.Module):
         # heads: h = [mu | raw]
         zp = pad16(self.z_dim)
         flat = a.view(B, L * pad16(ch[-1]))
-        h = self._buf("enc.h", (B, 2 * zp), zero=True)
-        self._lin("fc_mu", enc.fc_mu, B, ld_out=2 * zp).fwd(flat, enc.fc_mu.weight, enc.fc_mu.bias, h)
+        h = self._buf("enc.h", (B, self._hw), zero=True)
+        self._lin("fc_mu", enc.fc_mu, B, ld_out=self._hw).fwd(flat, enc.fc_mu.weight, enc.fc_mu.bias, h)
         fs = enc.fc_sigma[0]
-        self._lin("fc_sigma", fs, B, ld_out=2 * zp).fwd(flat, fs.weight, fs.bias, h[:, zp:])
+        self._lin("fc_sigma", fs, B, ld_out=self._hw).fwd(flat, fs.weight, fs.bias, h[:, zp:])
         return B, flat, h
 
     def _heads(self, B, h, eps):
@@ -437,8 +444,16 @@ class ResVAE(nn.Module):
         sigma = self._buf("sigma", (B, zp), zero=True)
         zc = self._buf("dec.zc", (B, zcp), zero=True)
         klp = self._buf("kl_part", (ops.heads_blocks(B, self.z_dim),))
-        ops.heads_diag_fwd(h, 2 * zp, eps, mu, sigma, zc, zcp, klp, B, self.z_dim, raw_off=zp, ldm=zp)
+        if self.is_diag:
+            ops.heads_diag_fwd(h, self._hw, eps, mu, sigma, zc, zcp, klp, B, self.z_dim, raw_off=zp, ldm=zp)
+            self._L = None
+        else:  # full Cholesky factor, materialised densely (it is part of the API: data_o["L"])
+            self._L = self._buf("L", (B, self.z_dim, self.z_dim))
+            ops.heads_tril_fwd(h, self._hw, eps, mu, zp, self._L, zc, zcp, klp, B, self.z_dim, zp)
         return mu, sigma, zc, klp
+
+    def _L_out(self, sigma):
+        return torch.diag_embed(sigma[:, : self.z_dim]) if self.is_diag else self._L
 
     def _conditional_var(self, data, B):
         parts = []
@@ -510,7 +525,7 @@ class ResVAE(nn.Module):
         B, flat, h = self._encode_trunk(data)
         mu, sigma, zc, klp = self._heads(B, h, None)
         self._state = dict(B=B, flat=flat, h=h, eps=None)
-        return {"mu": mu[:, : self.z_dim], "L": torch.diag_embed(sigma[:, : self.z_dim])}
+        return {"mu": mu[:, : self.z_dim], "L": self._L_out(sigma)}
 
     def decode(self, z, data):
         """ResVAE.decode (residual.py:461-491)."""
@@ -542,7 +557,7 @@ class ResVAE(nn.Module):
         if self.training:
             eps = self._prep(data["eps"]) if "eps" in data else self.sampling_noise(B)
         mu, sigma, zc, klp = self._heads(B, h, eps)
-        data_o = {"mu": mu[:, : self.z_dim], "L": torch.diag_embed(sigma[:, : self.z_dim])}
+        data_o = {"mu": mu[:, : self.z_dim], "L": self._L_out(sigma)}
         data_o["z"] = zc[:, : self.z_dim]
         if self.conditional_dim > 0:
             data_o["var"] = self._conditional_var(data, B)
@@ -665,15 +680,25 @@ class ResVAE(nn.Module):
         self._wgrad(lin, zc, g_f, dec.fc_in, acc)
         g_zc = self._buf("g.zc", (B, zcp))
         lin.dgrad(g_f, dec.fc_in.weight, g_zc)
+        # ---- data-parallel bucket 1: the decoder's gradients are final here; their all-reduce
+        # overlaps the encoder's reverse schedule (xGMI: few large transfers, not many small ones)
+        dec_work = None
+        if self.world_size > 1:
+            self._db_batch.flush(self._colsum_ws, accumulate=acc)
+            lo, hi = self._dec_span
+            dec_work = self._allreduce(self.flat_grads[lo:hi], async_op=True)
         # ---- heads: dh = [dmu | draw]
         h = st["h"]
-        dh = self._buf("g.h", (B, 2 * zp), zero=True)
-        ops.heads_diag_bwd(h, 2 * zp, st["eps"], st["sigma"], g_zc, zcp, d_mu, None, pend["kl_scale"], dh, B, self.z_dim,
-                           raw_off=zp, ldm=zp)
+        dh = self._buf("g.h", (B, self._hw), zero=True)
+        if self.is_diag:
+            ops.heads_diag_bwd(h, self._hw, st["eps"], st["sigma"], g_zc, zcp, d_mu, None, pend["kl_scale"], dh, B, self.z_dim,
+                               raw_off=zp, ldm=zp)
+        else:
+            ops.heads_tril_bwd(h, self._hw, st["eps"], self._L, g_zc, zcp, d_mu, zp, pend["kl_scale"], dh, B, self.z_dim, zp)
         flat = st["flat"]
         fm, fs = enc.fc_mu, enc.fc_sigma[0]
-        lm = self._lin("fc_mu", fm, B, ld_out=2 * zp)
-        ls = self._lin("fc_sigma", fs, B, ld_out=2 * zp)
+        lm = self._lin("fc_mu", fm, B, ld_out=self._hw)
+        ls = self._lin("fc_sigma", fs, B, ld_out=self._hw)
         self._wgrad(lm, flat, dh, fm, acc)
         self._wgrad(ls, flat, dh[:, zp:], fs, acc)
         g_flat = self._buf("g.flat", tuple(flat.shape))
@@ -725,5 +750,11 @@ class ResVAE(nn.Module):
         self._db_batch.flush(self._colsum_ws, accumulate=acc)
         # ---- data-parallel: sum gradients over ranks (losses are normalised by the GLOBAL batch)
         if self.world_size > 1:
-            self._allreduce(self.flat_grads)
+            lo, hi = self._dec_span
+            if lo > 0:
+                self._allreduce(self.flat_grads[:lo])
+            if hi < self.flat_grads.numel():
+                self._allreduce(self.flat_grads[hi:])
+            if dec_work is not None:
+                dec_work.wait()
         self._pending = None

@@ -351,6 +351,16 @@ def heads_diag_bwd(h, ld, eps, sigma, dz, lddz, dmu, dsigma, kl_scale, dh, batch
                                          batch, zdim, zdim if raw_off is None else raw_off, ldm or zdim, _stream()), "heads_diag_bwd")
 
 
+def heads_tril_fwd(h, ld, eps, mu, ldm, L, z, ldz, kl_part, batch, zdim, raw_off):
+    check(_lib.lib().svae_heads_tril_fwd(_p(h), ld, _p(eps), _p(mu), ldm, _p(L), _p(z), ldz, _p(kl_part), batch, zdim, raw_off,
+                                         _stream()), "heads_tril_fwd")
+
+
+def heads_tril_bwd(h, ld, eps, L, dz, lddz, dmu, ldm, kl_scale, dh, batch, zdim, raw_off):
+    check(_lib.lib().svae_heads_tril_bwd(_p(h), ld, _p(eps), _p(L), _p(dz), lddz, _p(dmu), ldm, float(kl_scale), _p(dh), batch,
+                                         zdim, raw_off, _stream()), "heads_tril_bwd")
+
+
 def tail_blocks(rows):
     return int(_lib.lib().svae_tail_blocks(rows))
 

@@ -39,7 +39,7 @@ def to_dev(data):
     return {k: v.cuda() for k, v in data.items()}
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "rotation_tiny", "vanilla_default_B4"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "rotation_tiny", "fullL_ids_tiny", "vanilla_default_B4"])
 def test_step0_matches_reference_fixture(golden_dir, name):
     from scrubvae_amd.train.losses import get_batch_loss
     fx, cfg, loss_scale, opt, sd, data = load_fixture(golden_dir, name)
