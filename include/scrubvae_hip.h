@@ -163,9 +163,22 @@ int svae_heads_diag_bwd(const float* h, int ld, const float* eps, const float* s
  * kl_part as above with diag(L L^T) = row sums of squares. */
 int svae_heads_tril_fwd(const float* h, int ld, const float* eps, float* mu, int ldm, float* L, float* z,
                         int ldz, float* kl_part, int batch, int zdim, int raw_off, void* stream);
+/* dlv (optional, [B,z]): upstream gradient w.r.t. log diag(L L^T) (total-correlation loss) */
 int svae_heads_tril_bwd(const float* h, int ld, const float* eps, const float* L, const float* dz, int lddz,
-                        const float* dmu, int ldm, float kl_scale, float* dh, int batch, int zdim,
-                        int raw_off, void* stream);
+                        const float* dmu, int ldm, float kl_scale, const float* dlv, float* dh, int batch,
+                        int zdim, int raw_off, void* stream);
+
+/* L5: total_correlation (losses.py:41-101), beta-TCVAE minibatch estimator, z detached.
+ * svae_tc_logvar: lv[b,l] = log diag(L L^T) from sigma (diag; 2 log sigma) or a dense L.
+ * svae_tc_fwd: loss[j] (TC = mean_j), plus the two log-sum-exp tables the backward reuses
+ * (lse_l [B,z], lse_a [B]).  svae_tc_bwd: d_mu[i,:] += weight * dTCsum/dmu, d_lv = weight *
+ * dTCsum/dlv (weight = loss_scale / B).  O(B^2 z), nothing of size [B,B,z] is materialised. */
+int svae_tc_logvar(const float* sigma, int lds, const float* L, float* lv, int batch, int zdim, void* stream);
+int svae_tc_fwd(const float* z, int ldz, const float* mu, int ldm, const float* lv, int batch, int zdim,
+                float* lse_l, float* lse_a, float* loss, void* stream);
+int svae_tc_bwd(const float* z, int ldz, const float* mu, int ldm, const float* lv, int batch, int zdim,
+                const float* lse_l, const float* lse_a, float weight, float* d_mu, int ldd, float* d_lv,
+                int ldv, const float* sigma /* optional: emit d/dsigma = d/dlv*2/sigma */, int lds, void* stream);
 
 /* ----------------------------------------------------------------- pose-loss tail --- */
 typedef struct {

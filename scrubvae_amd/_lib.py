@@ -79,7 +79,10 @@ SIGNATURES = {
     "svae_heads_blocks": (I, [I, I]),
     "svae_heads_diag_bwd": (I, [P, I, P, P, P, I, P, P, F, P, I, I, I, I, P]),
     "svae_heads_tril_fwd": (I, [P, I, P, P, I, P, P, I, P, I, I, I, P]),
-    "svae_heads_tril_bwd": (I, [P, I, P, P, P, I, P, I, F, P, I, I, I, P]),
+    "svae_heads_tril_bwd": (I, [P, I, P, P, P, I, P, I, F, P, P, I, I, I, P]),
+    "svae_tc_logvar": (I, [P, I, P, P, I, I, P]),
+    "svae_tc_fwd": (I, [P, I, P, I, P, I, I, P, P, P, P]),
+    "svae_tc_bwd": (I, [P, I, P, I, P, I, I, P, P, F, P, I, P, I, P, I, P]),
     "svae_tail_blocks": (I, [LL]),
     "svae_pose_tail": (I, [P, I, P, P, P, C.POINTER(F), C.POINTER(Tree), F, F, P, P, P, P, P, P, P, LL, I, P]),
     "svae_rot_loss": (I, [P, P, F, P, P, LL, P]),

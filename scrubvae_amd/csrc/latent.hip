@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void heads_tril_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void heads_tril_bwd_kernel(const float* __restrict__ h, int ld, const float* __restrict__ eps,
                                                               const float* __restrict__ L, const float* __restrict__ dz, int lddz,
                                                               const float* __restrict__ dmu, int ldm, float kl_scale,
+                                                              const float* __restrict__ dlv,
                                                               float* __restrict__ dh, int batch, int zd, int raw_off) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= (long long)batch * zd) return;
@@ -59,10 +60,165 @@ __global__ __launch_bounds__(256) void heads_tril_bwd_kernel(const float* __rest
   float gm = gz + kl_scale * hb[i];
   if (dmu) gm += dmu[(long long)b * ldm + i];
   dhb[i] = gm;
-  for (int j = 0; j < i; ++j) dhb[ro + j] = (eps ? gz * eps[(long long)b * zd + j] : 0.f) + kl_scale * Lr[j];
+  // lv_i = log(sum_j L_ij^2): an upstream d/d lv_i reaches L_ij as dlv_i * 2 L_ij / rowss_i
+  float lvk = 0.f;
+  if (dlv != nullptr) {
+    float ssq = 0.f;
+    for (int j = 0; j <= i; ++j) ssq += Lr[j] * Lr[j];
+    lvk = 2.f * dlv[(long long)b * zd + i] / ssq;
+  }
+  for (int j = 0; j < i; ++j) dhb[ro + j] = (eps ? gz * eps[(long long)b * zd + j] : 0.f) + (kl_scale + lvk) * Lr[j];
   const float d = Lr[i];
-  const float gd = (eps ? gz * eps[(long long)b * zd + i] : 0.f) + kl_scale * (d - 1.f / d);
+  const float gd = (eps ? gz * eps[(long long)b * zd + i] : 0.f) + kl_scale * (d - 1.f / d) + lvk * d;
   dhb[ro + i] = gd / (1.f + expf(-hb[ro + i]));
+}
+
+// ------------------------------------------------------------------ total correlation
+// beta-TCVAE minibatch estimator (reference losses.py:41-101):
+//   lq[j,i,l] = -0.5*(exp(-lv[i,l])*(z[j,l]-mu[i,l])^2 + lv[i,l] + log(2 pi)),  z detached
+//   loss_j = logsumexp_i(sum_l lq[j,i,l]) - sum_l logsumexp_i(lq[j,i,l]);  TC = mean_j loss_j
+// One workgroup per sample j; 8 groups of 32 lanes: lane = latent dim (chunks of 32), group =
+// stripe of the i loop.  Online logsumexp per lane (over i) and per group (over i of the
+// lane-summed a_i); O(B^2 z) work, no [B,B,z] tensor is ever materialised.
+constexpr float LN2PI_F = 1.8378770664093453f;
+constexpr int TC_MAXCH = 4;  // z_dim <= 128
+
+__device__ __forceinline__ void lse_push(float& m, float& s, float x) {
+  if (x > m) { s = s * expf(m - x) + 1.f; m = x; }
+  else s += expf(x - m);
+}
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+  if (m2 > m) { s = s * expf(m - m2) + s2; m = m2; }
+  else s += s2 * expf(m2 - m);
+}
+__device__ __forceinline__ float half_sum32(float v) {  // sum over the 32 lanes of a half-wave
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void tc_prep_kernel(const float* __restrict__ sigma, int lds, const float* __restrict__ L,
+                                                       float* __restrict__ lv, int batch, int zd) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)batch * zd) return;
+  const int b = (int)(t / zd), i = (int)(t - (long long)b * zd);
+  if (L == nullptr) {
+    lv[t] = 2.f * logf(sigma[(long long)b * lds + i]);
+  } else {
+    const float* r = L + ((long long)b * zd + i) * zd;
+    float ss = 0.f;
+    for (int j = 0; j <= i; ++j) ss += r[j] * r[j];
+    lv[t] = logf(ss);
+  }
+}
+
+__global__ __launch_bounds__(256) void tc_fwd_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ mu, int ldm,
+                                                      const float* __restrict__ lv, int batch, int zd, float* __restrict__ lse_l,
+                                                      float* __restrict__ lse_a, float* __restrict__ loss) {
+  __shared__ float sm[8][TC_MAXCH * 32], ss[8][TC_MAXCH * 32], sM[8], sT[8], red4[4];
+  const int j = blockIdx.x, lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int nch = (zd + 31) / 32;
+  float zj[TC_MAXCH], m[TC_MAXCH], s[TC_MAXCH];
+#pragma unroll
+  for (int c = 0; c < TC_MAXCH; ++c) {
+    const int l = c * 32 + lane;
+    zj[c] = (c < nch && l < zd) ? z[(long long)j * ldz + l] : 0.f;
+    m[c] = -3.0e38f;
+    s[c] = 0.f;
+  }
+  float M = -3.0e38f, T = 0.f;
+  for (int i = grp; i < batch; i += 8) {
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < TC_MAXCH; ++c) {
+      const int l = c * 32 + lane;
+      if (c < nch && l < zd) {
+        const float v = lv[(long long)i * zd + l], d = zj[c] - mu[(long long)i * ldm + l];
+        const float q = -0.5f * (expf(-v) * d * d + v + LN2PI_F);
+        lse_push(m[c], s[c], q);
+        a += q;
+      }
+    }
+    a = half_sum32(a);
+    lse_push(M, T, a);
+  }
+#pragma unroll
+  for (int c = 0; c < TC_MAXCH; ++c) { sm[grp][c * 32 + lane] = m[c]; ss[grp][c * 32 + lane] = s[c]; }
+  if (lane == 0) { sM[grp] = M; sT[grp] = T; }
+  __syncthreads();
+  float prod = 0.f;
+  if (threadIdx.x < zd) {
+    float mm = sm[0][threadIdx.x], s2 = ss[0][threadIdx.x];
+    for (int g2 = 1; g2 < 8; ++g2) lse_merge(mm, s2, sm[g2][threadIdx.x], ss[g2][threadIdx.x]);
+    const float l = mm + logf(s2);
+    lse_l[(long long)j * zd + threadIdx.x] = l;
+    prod = l;
+  }
+  const float tot = block_sum_256(prod, red4);
+  if (threadIdx.x == 0) {
+    float mm = sM[0], s2 = sT[0];
+    for (int g2 = 1; g2 < 8; ++g2) lse_merge(mm, s2, sM[g2], sT[g2]);
+    const float la = mm + logf(s2);
+    lse_a[j] = la;
+    loss[j] = la - tot;
+  }
+}
+
+// gradient w.r.t. mu[i,:] and lv[i,:] (z is detached): one workgroup per i, loop over j
+__global__ __launch_bounds__(256) void tc_bwd_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ mu, int ldm,
+                                                      const float* __restrict__ lv, int batch, int zd,
+                                                      const float* __restrict__ lse_l, const float* __restrict__ lse_a, float w,
+                                                      float* __restrict__ d_mu, int ldd, float* __restrict__ d_lv, int ldv,
+                                                      const float* __restrict__ sigma, int lds) {
+  __shared__ float g1[8][TC_MAXCH * 32], g2s[8][TC_MAXCH * 32];
+  const int i = blockIdx.x, lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int nch = (zd + 31) / 32;
+  float mi[TC_MAXCH], vi[TC_MAXCH], ei[TC_MAXCH], gm[TC_MAXCH], gv[TC_MAXCH];
+#pragma unroll
+  for (int c = 0; c < TC_MAXCH; ++c) {
+    const int l = c * 32 + lane;
+    const bool ok = c < nch && l < zd;
+    mi[c] = ok ? mu[(long long)i * ldm + l] : 0.f;
+    vi[c] = ok ? lv[(long long)i * zd + l] : 0.f;
+    ei[c] = expf(-vi[c]);
+    gm[c] = gv[c] = 0.f;
+  }
+  for (int j = grp; j < batch; j += 8) {
+    float q[TC_MAXCH], d[TC_MAXCH];
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < TC_MAXCH; ++c) {
+      const int l = c * 32 + lane;
+      q[c] = 0.f; d[c] = 0.f;
+      if (c < nch && l < zd) {
+        d[c] = z[(long long)j * ldz + l] - mi[c];
+        q[c] = -0.5f * (ei[c] * d[c] * d[c] + vi[c] + LN2PI_F);
+        a += q[c];
+      }
+    }
+    a = half_sum32(a);
+    const float p = expf(a - lse_a[j]);
+#pragma unroll
+    for (int c = 0; c < TC_MAXCH; ++c) {
+      const int l = c * 32 + lane;
+      if (c < nch && l < zd) {
+        const float g = w * (p - expf(q[c] - lse_l[(long long)j * zd + l]));
+        gm[c] += g * ei[c] * d[c];
+        gv[c] += g * 0.5f * (ei[c] * d[c] * d[c] - 1.f);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < TC_MAXCH; ++c) { g1[grp][c * 32 + lane] = gm[c]; g2s[grp][c * 32 + lane] = gv[c]; }
+  __syncthreads();
+  if (threadIdx.x < zd) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int g = 0; g < 8; ++g) { a1 += g1[g][threadIdx.x]; a2 += g2s[g][threadIdx.x]; }
+    d_mu[(long long)i * ldd + threadIdx.x] += a1;
+    // diagonal posterior: lv = 2 log sigma, so hand back d/d sigma = d/d lv * 2 / sigma
+    if (sigma != nullptr) a2 *= 2.f / sigma[(long long)i * lds + threadIdx.x];
+    d_lv[(long long)i * ldv + threadIdx.x] = a2;
+  }
 }
 
 }  // namespace svae
@@ -80,10 +236,36 @@ extern "C" int svae_heads_tril_fwd(const float* h, int ld, const float* eps, flo
 }
 
 extern "C" int svae_heads_tril_bwd(const float* h, int ld, const float* eps, const float* L, const float* dz, int lddz,
-                                   const float* dmu, int ldm, float kl_scale, float* dh, int batch, int zdim, int raw_off,
-                                   void* stream) {
+                                   const float* dmu, int ldm, float kl_scale, const float* dlv, float* dh, int batch, int zdim,
+                                   int raw_off, void* stream) {
   SVAE_REQUIRE(h && L && dh && batch > 0 && zdim > 0, SVAE_ERR_ARG, "heads_tril_bwd: bad args");
   hipLaunchKernelGGL(heads_tril_bwd_kernel, dim3(svae_heads_blocks(batch, zdim)), dim3(256), 0, (hipStream_t)stream, h, ld, eps, L,
-                     dz, lddz, dmu, ldm, kl_scale, dh, batch, zdim, raw_off);
+                     dz, lddz, dmu, ldm, kl_scale, dlv, dh, batch, zdim, raw_off);
   return check_launch("heads_tril_bwd");
+}
+
+extern "C" int svae_tc_logvar(const float* sigma, int lds, const float* L, float* lv, int batch, int zdim, void* stream) {
+  SVAE_REQUIRE((sigma || L) && lv && batch > 0 && zdim > 0, SVAE_ERR_ARG, "tc_logvar: bad args");
+  hipLaunchKernelGGL(tc_prep_kernel, dim3(svae_heads_blocks(batch, zdim)), dim3(256), 0, (hipStream_t)stream, sigma, lds, L, lv,
+                     batch, zdim);
+  return check_launch("tc_logvar");
+}
+
+extern "C" int svae_tc_fwd(const float* z, int ldz, const float* mu, int ldm, const float* lv, int batch, int zdim,
+                           float* lse_l, float* lse_a, float* loss, void* stream) {
+  SVAE_REQUIRE(z && mu && lv && lse_l && lse_a && loss && batch > 0 && zdim > 0 && zdim <= 32 * TC_MAXCH, SVAE_ERR_ARG,
+               "tc_fwd: bad args (z_dim must be <= %d)", 32 * TC_MAXCH);
+  hipLaunchKernelGGL(tc_fwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, z, ldz, mu, ldm, lv, batch, zdim, lse_l, lse_a,
+                     loss);
+  return check_launch("tc_fwd");
+}
+
+extern "C" int svae_tc_bwd(const float* z, int ldz, const float* mu, int ldm, const float* lv, int batch, int zdim,
+                           const float* lse_l, const float* lse_a, float weight, float* d_mu, int ldd, float* d_lv, int ldv,
+                           const float* sigma, int lds, void* stream) {
+  SVAE_REQUIRE(z && mu && lv && lse_l && lse_a && d_mu && d_lv && batch > 0 && zdim > 0 && zdim <= 32 * TC_MAXCH, SVAE_ERR_ARG,
+               "tc_bwd: bad args");
+  hipLaunchKernelGGL(tc_bwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, z, ldz, mu, ldm, lv, batch, zdim, lse_l, lse_a,
+                     weight, d_mu, ldd, d_lv, ldv, sigma, lds);
+  return check_launch("tc_bwd");
 }

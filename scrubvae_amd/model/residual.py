@@ -691,10 +691,11 @@ class ResVAE(nn.Module):
         h = st["h"]
         dh = self._buf("g.h", (B, self._hw), zero=True)
         if self.is_diag:
-            ops.heads_diag_bwd(h, self._hw, st["eps"], st["sigma"], g_zc, zcp, d_mu, None, pend["kl_scale"], dh, B, self.z_dim,
-                               raw_off=zp, ldm=zp)
+            ops.heads_diag_bwd(h, self._hw, st["eps"], st["sigma"], g_zc, zcp, d_mu, pend.get("dsigma"), pend["kl_scale"], dh, B,
+                               self.z_dim, raw_off=zp, ldm=zp)
         else:
-            ops.heads_tril_bwd(h, self._hw, st["eps"], self._L, g_zc, zcp, d_mu, zp, pend["kl_scale"], dh, B, self.z_dim, zp)
+            ops.heads_tril_bwd(h, self._hw, st["eps"], self._L, g_zc, zcp, d_mu, zp, pend["kl_scale"], pend.get("dlv"), dh, B,
+                               self.z_dim, zp)
         flat = st["flat"]
         fm, fs = enc.fc_mu, enc.fc_sigma[0]
         lm = self._lin("fc_mu", fm, B, ld_out=self._hw)

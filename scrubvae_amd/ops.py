@@ -356,9 +356,22 @@ def heads_tril_fwd(h, ld, eps, mu, ldm, L, z, ldz, kl_part, batch, zdim, raw_off
                                          _stream()), "heads_tril_fwd")
 
 
-def heads_tril_bwd(h, ld, eps, L, dz, lddz, dmu, ldm, kl_scale, dh, batch, zdim, raw_off):
-    check(_lib.lib().svae_heads_tril_bwd(_p(h), ld, _p(eps), _p(L), _p(dz), lddz, _p(dmu), ldm, float(kl_scale), _p(dh), batch,
-                                         zdim, raw_off, _stream()), "heads_tril_bwd")
+def heads_tril_bwd(h, ld, eps, L, dz, lddz, dmu, ldm, kl_scale, dlv, dh, batch, zdim, raw_off):
+    check(_lib.lib().svae_heads_tril_bwd(_p(h), ld, _p(eps), _p(L), _p(dz), lddz, _p(dmu), ldm, float(kl_scale), _p(dlv), _p(dh),
+                                         batch, zdim, raw_off, _stream()), "heads_tril_bwd")
+
+
+def tc_logvar(sigma, lds, L, lv, batch, zdim):
+    check(_lib.lib().svae_tc_logvar(_p(sigma), lds, _p(L), _p(lv), batch, zdim, _stream()), "tc_logvar")
+
+
+def tc_fwd(z, ldz, mu, ldm, lv, batch, zdim, lse_l, lse_a, loss):
+    check(_lib.lib().svae_tc_fwd(_p(z), ldz, _p(mu), ldm, _p(lv), batch, zdim, _p(lse_l), _p(lse_a), _p(loss), _stream()), "tc_fwd")
+
+
+def tc_bwd(z, ldz, mu, ldm, lv, batch, zdim, lse_l, lse_a, weight, d_mu, ldd, d_lv, ldv, sigma=None, lds=0):
+    check(_lib.lib().svae_tc_bwd(_p(z), ldz, _p(mu), ldm, _p(lv), batch, zdim, _p(lse_l), _p(lse_a), float(weight), _p(d_mu), ldd,
+                                 _p(d_lv), ldv, _p(sigma), lds, _stream()), "tc_bwd")
 
 
 def tail_blocks(rows):

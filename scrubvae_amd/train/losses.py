@@ -21,7 +21,7 @@ import torch
 from .. import ops
 from ..ops import pad16
 
-SUPPORTED = ("rotation", "prior", "jpe", "root")
+SUPPORTED = ("rotation", "prior", "jpe", "root", "total_correlation")
 
 
 def _scalar(model, name):
@@ -172,8 +172,32 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
             else:
                 raise NotImplementedError(f"scrubber '{method}' is outside this build's scope (SURVEY 8a row A2)")
 
+    # ---- total correlation (L5): O(B^2 z) estimator over the local batch, z detached
+    dsigma = dlv = None
+    if "total_correlation" in loss_scale:
+        if z > 128:
+            raise NotImplementedError("total_correlation kernel supports z_dim <= 128")
+        zc, zcp = st["zc"], st["zc"].shape[1]
+        mu_b, sig = st["mu"], st["sigma"]
+        lv = model._buf("tc.lv", (B, z))
+        ops.tc_logvar(sig if model.is_diag else None, zp, None if model.is_diag else model._L, lv, B, z)
+        lse_l, lse_a, lj = model._buf("tc.lse_l", (B, z)), model._buf("tc.lse_a", (B,)), model._buf("tc.loss", (B,))
+        ops.tc_fwd(zc, zcp, mu_b, zp, lv, B, z, lse_l, lse_a, lj)
+        v = _scalar(model, "total_correlation")
+        ops.reduce_rows(lj, B, 1, 1.0 / B, v)
+        batch_loss["total_correlation"] = v.view(()).clone()
+        add_total("total_correlation", v)
+        if train and loss_scale["total_correlation"] != 0:
+            w = float(loss_scale["total_correlation"]) / (B * world)
+            if model.is_diag:
+                dsigma = model._buf("tc.dsigma", (B, zp), zero=True)
+                ops.tc_bwd(zc, zcp, mu_b, zp, lv, B, z, lse_l, lse_a, w, d_mu, zp, dsigma, zp, sig, zp)
+            else:
+                dlv = model._buf("tc.dlv", (B, z))
+                ops.tc_bwd(zc, zcp, mu_b, zp, lv, B, z, lse_l, lse_a, w, d_mu, zp, dlv, z)
+
     if train:
-        model._pending = dict(dy=dy, kl_scale=kl_scale, d_mu=d_mu, scrub=scrub,
+        model._pending = dict(dy=dy, kl_scale=kl_scale, d_mu=d_mu, scrub=scrub, dsigma=dsigma, dlv=dlv,
                               accumulate=getattr(model, "accumulate_grads", False))
         batch_loss["total"] = model.make_total(total.view(()))
     else:

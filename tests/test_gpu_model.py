@@ -39,7 +39,7 @@ def to_dev(data):
     return {k: v.cuda() for k, v in data.items()}
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "rotation_tiny", "fullL_ids_tiny", "vanilla_default_B4"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "rotation_tiny", "fullL_ids_tiny", "tc_tiny", "vanilla_default_B4"])
 def test_step0_matches_reference_fixture(golden_dir, name):
     from scrubvae_amd.train.losses import get_batch_loss
     fx, cfg, loss_scale, opt, sd, data = load_fixture(golden_dir, name)
@@ -207,3 +207,30 @@ def test_reference_style_loop_with_torch_optimizer():
     assert m1["total"] < m0["total"]  # it learns
     mt = train_test_epoch(config, model, loader, "cuda", 2, None, None, "test")
     assert np.isfinite(mt["total"])
+
+
+def test_oracle_parity_full_cholesky_total_correlation():
+    """model.diag=False + beta-TCVAE total correlation (losses.py:41-101) vs the CPU oracle."""
+    from scrubvae_amd.train.losses import get_batch_loss
+    cfg = O.OracleConfig(n_keypts=18, window=64, z_dim=8, kernel=5, channel=(8, 8, 16, 16, 32), diag=False, arena_size=ARENA)
+    sd = O.init_state_dict(cfg, seed=21)
+    data = O.synth_batch(cfg, 12, seed=21)
+    eps = torch.randn(12, 8, generator=torch.Generator().manual_seed(2))
+    ls = {"jpe": 1.0, "root": 1.0, "prior": 0.5, "total_correlation": 0.7}
+    bl_o, g_o, _, out_o = O.train_step(sd, cfg, data, ls, eps)
+    model, dis = build_model(cfg, sd)
+    model.train()
+    d = to_dev(data)
+    d["eps"] = eps.cuda()
+    data_o = model(d)
+    bl = get_batch_loss(model, d, data_o, ls, dis)
+    bl["total"].backward()
+    for k in ("mu", "L", "z", "x6d", "root"):
+        assert rel(data_o[k].cpu(), out_o[k].detach()) < 2e-5, k
+    for k in bl_o:
+        assert rel(bl[k].detach().cpu(), bl_o[k]) < 1e-4, k
+    grads = {k: v.cpu() for k, v in model.grads_state_dict().items()}
+    gmax = max(float(g.abs().max()) for g in g_o.values())
+    for n, g in g_o.items():
+        dd = float((grads[n] - g).abs().max()) / (float(g.abs().max()) + 1e-3 * gmax)
+        assert dd < 2e-2, (n, dd)
