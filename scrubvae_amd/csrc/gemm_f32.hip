@@ -22,6 +22,7 @@
 // Two LDS stages + register prefetch (global loads of tile k+1 are issued before the MFMAs
 // of tile k, written to LDS after them): one barrier per K tile.
 #include "svae_internal.h"
+#include <type_traits>
 
 namespace svae {
 
@@ -118,14 +119,14 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
     const int c0 = nx_c0;
     const int tb = nx_tb;
     const float* wt = g.W + nx_woff;
-    nx_c0 += BK;
-    if (nx_c0 == g.Kc) {
-      nx_c0 = 0;
-      ++nx_ti;
-      if (nx_ti < ntaps) {
-        nx_tb = tap_base[nx_ti];
-        nx_woff = (long long)tap_w[nx_ti] * g.w_tap_stride;
-      }
+    {  // branch-free advance (uniform selects + one scalar table load per tile)
+      nx_c0 += BK;
+      const bool wrap = nx_c0 == g.Kc;
+      nx_c0 = wrap ? 0 : nx_c0;
+      nx_ti += wrap ? 1 : 0;
+      const int tic = nx_ti < ntaps ? nx_ti : ntaps - 1;
+      nx_tb = tap_base[tic];
+      nx_woff = (long long)tap_w[tic] * g.w_tap_stride;
     }
     // branch-free: clamped address + select, so the whole K-tile body is ONE basic block and
     // the scheduler can slide these loads between the MFMAs
@@ -187,19 +188,24 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // software pipeline: tile k is in LDS, tile k+1 is in flight in registers.  In the middle of
+  // tile k's MFMAs the registers are written to the other LDS stage and immediately re-issued
+  // for tile k+2: global-load latency gets a whole tile of MFMAs, the ds_writes hide under the
+  // second MFMA half, and only a bare barrier is left at the end of the iteration.
   if (nk > 0) {
     load_tile();
     store_tile(0);
+    if (nk > 1) load_tile();
   }
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
+  // One K tile.  DoStore/DoLoad are compile-time so that the steady-state loop body is a single
+  // basic block: the compiler is then free to slide the staging instructions (selects, ds_write,
+  // address maths, global loads) in between the MFMAs instead of clumping them.
+  auto k_tile = [&](int kt, auto do_store, auto do_load) {
     const int buf = kt & 1;
     const float* as = As[buf];
     const float* bs = Bs[buf];
-    // all LDS fragment reads of the K tile are issued up front (32 VGPRs); the MFMAs start as
-    // soon as the first fragments land.  The global loads (+ address maths) of the NEXT tile sit
-    // between the two MFMA halves, where the matrix pipe is busy for ~1000 cycles anyway.
     float4 av[2][MT], bv[2][NT];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -215,7 +221,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (decltype(do_store)::value) store_tile(buf ^ 1);
+    if constexpr (decltype(do_load)::value) load_tile();
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
 #pragma unroll
@@ -230,14 +237,14 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
           }
         }
       }
-      if (q == 0) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) load_tile();
-        __builtin_amdgcn_sched_barrier(0);
-      }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();
+  };
+  {
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) k_tile(kt, std::true_type{}, std::true_type{});
+    if (kt + 1 < nk) { k_tile(kt, std::true_type{}, std::false_type{}); ++kt; }
+    if (kt < nk) k_tile(kt, std::false_type{}, std::false_type{});
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
@@ -375,11 +382,11 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
   if (nk > 0) {
     load_tile(r_begin);
     store_tile(0);
+    if (nk > 1) load_tile(r_begin + BK);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(r_begin + (long long)(kt + 1) * BK);
     const float* as = As[buf];
     const float* bs = Bs[buf];
     float av[2][MT][4], bv[2][NT][4];
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
       }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -402,7 +409,13 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][mt][jj], bv[q][nt][jj], acc[mt][nt], 0, 0, 0);
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+      if (q == 0) {  // mid-tile: registers -> other LDS stage, then re-issue them for tile k+2
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        if (kt + 2 < nk) load_tile(r_begin + (long long)(kt + 2) * BK);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     __syncthreads();
   }
 
