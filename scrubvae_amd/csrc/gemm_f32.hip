@@ -14,8 +14,9 @@
 //
 // Data layout: activations channels-last [B*L][ld]; weights w[tap][c_in][c_out].
 // Math: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).
-// Tile: 128 x BN x 16 per workgroup of 4 waves (2x2), each wave 64 x BN/2 = 2 x (BN/64)
-// MFMA tiles.  K-contiguous operands sit in LDS as [row][16+4] and are fetched with one
+// Tile: BM x BN (64/128 each) per workgroup of 4 waves (2x2); the gather kernel stages 32-deep
+// K tiles (each A row segment is one full 128-byte line), the weight-gradient kernel 16-deep
+// ones.  K-contiguous operands sit in LDS as [row][K+4] and are fetched with one
 // ds_read_b128 per 4 k-steps: the k order inside an 8-chunk is permuted (lane half h holds
 // k = 8q+4h+j) which is legal because both operands use the same permutation.
 // Row-contiguous operands sit as [k][cols] and are fetched with conflict-free ds_read_b32.
@@ -53,16 +54,21 @@ struct GatherArgs {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+constexpr int GBK = 32;         // K depth of one LDS stage of the gather kernel (two 16-deep halves)
+constexpr int GLDK = GBK + 4;   // padded row of a K-contiguous tile: conflict-free ds_read_b128
+
 template <int BM, int BN, bool B_KC>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
   constexpr int WM = BM / 2;   // wave tile rows
   constexpr int MT = WM / 32;  // MFMA tiles down
-  constexpr int APASS = BM / 64;
   constexpr int WN = BN / 2;   // wave tile columns
   constexpr int NT = WN / 32;  // MFMA tiles across
-  constexpr int B_ELEMS = B_KC ? BN * LDK : BK * BN;
-  constexpr int BPASS = BN / 64;  // float4 per thread for the B tile
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+  constexpr int APASS = BM / 32;                      // float4 per thread for the A tile (8 per row)
+  constexpr int B_ELEMS = B_KC ? BN * GLDK : GBK * BN;
+  constexpr int F4_PER_ROW = BN / 4;                  // row-contiguous B: float4 per k-row
+  constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+  constexpr int BPASS = B_KC ? BN / 32 : GBK / ROWS_PER_PASS;
+  __shared__ __attribute__((aligned(16))) float As[2][BM * GLDK];
   __shared__ __attribute__((aligned(16))) float Bs[2][B_ELEMS];
   __shared__ long long rowoff[BM];
 
@@ -77,17 +83,17 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
   const int* __restrict__ tap_base = g.base[phase];
   const int* __restrict__ tap_w = g.widx[phase];
 
-  // ---- per-thread A rows (2 rows, one 16-byte column slot each)
-  const int akq = tid & 3;
+  // ---- per-thread A rows: 8 lanes cover one 128-byte row segment (a full cache line)
+  const int akq = tid & 7;
   long long a_off[APASS];
   int a_j[APASS];
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
-    const long long m = m0 + (tid >> 2) + 64 * i;
+    const long long m = m0 + (tid >> 3) + 32 * i;
     if (m < Mp) {
       const long long b = m / nj;
       const int j = (int)(m - b * nj);
-      a_off[i] = b * (long long)g.Lin * g.ldA + akq * 4;
+      a_off[i] = b * (long long)g.Lin * g.ldA;
       a_j[i] = j * g.sj;
     } else {
       a_off[i] = 0;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
     rowoff[tid] = off;
   }
 
-  const int tiles_per_tap = g.Kc / BK;
+  const int tiles_per_tap = (g.Kc + GBK - 1) / GBK;  // the last tile of a tap may be half full
   const int nk = ntaps * tiles_per_tap;
 
   float4 ra[APASS], rb[BPASS];
@@ -120,56 +126,54 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
     const int tb = nx_tb;
     const float* wt = g.W + nx_woff;
     {  // branch-free advance (uniform selects + one scalar table load per tile)
-      nx_c0 += BK;
-      const bool wrap = nx_c0 == g.Kc;
+      nx_c0 += GBK;
+      const bool wrap = nx_c0 >= g.Kc;
       nx_c0 = wrap ? 0 : nx_c0;
       nx_ti += wrap ? 1 : 0;
       const int tic = nx_ti < ntaps ? nx_ti : ntaps - 1;
       nx_tb = tap_base[tic];
       nx_woff = (long long)tap_w[tic] * g.w_tap_stride;
     }
-    // branch-free: clamped address + select, so the whole K-tile body is ONE basic block and
-    // the scheduler can slide these loads between the MFMAs
+    // branch-free loads: clamped address now, zero-select when the registers go to LDS
+    const bool kq_ok = c0 + akq * 4 < g.Kc;
+    const int cq = kq_ok ? c0 + akq * 4 : 0;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const int li = a_j[i] + tb;
       const bool ok = li >= 0 && li < g.Lin;
       const int lic = ok ? li : 0;
-      ra[i] = ld4(g.A + a_off[i] + (long long)lic * g.ldA + c0);
-      ra_ok[i] = ok;
+      ra[i] = ld4(g.A + a_off[i] + (long long)lic * g.ldA + cq);
+      ra_ok[i] = ok && kq_ok;
     }
     if constexpr (B_KC) {
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
-        const int n = n0 + (tid >> 2) + 64 * i;
+        const int n = n0 + (tid >> 3) + 32 * i;
         const bool ok = n < g.N;
-        rb[i] = ld4(wt + (long long)(ok ? n : 0) * g.ldW + c0 + akq * 4);
-        rb_ok[i] = ok;
+        rb[i] = ld4(wt + (long long)(ok ? n : 0) * g.ldW + cq);
+        rb_ok[i] = ok && kq_ok;
       }
     } else {
-      constexpr int F4_PER_ROW = BN / 4;
-      constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
       const int n = n0 + (tid % F4_PER_ROW) * 4;
       const bool ok = n < g.N;
       const int nc = ok ? n : 0;
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
         const int k = tid / F4_PER_ROW + ROWS_PER_PASS * i;
-        rb[i] = ld4(wt + (long long)(c0 + k) * g.ldW + nc);
-        rb_ok[i] = ok;
+        const bool kok = c0 + k < g.Kc;
+        rb[i] = ld4(wt + (long long)(kok ? c0 + k : 0) * g.ldW + nc);
+        rb_ok[i] = ok && kok;
       }
     }
   };
   auto store_tile = [&](int buf) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < APASS; ++i) st4(&As[buf][((tid >> 2) + 64 * i) * LDK + akq * 4], ra_ok[i] ? ra[i] : zero4);
+    for (int i = 0; i < APASS; ++i) st4(&As[buf][((tid >> 3) + 32 * i) * GLDK + akq * 4], ra_ok[i] ? ra[i] : zero4);
     if constexpr (B_KC) {
 #pragma unroll
-      for (int i = 0; i < BPASS; ++i) st4(&Bs[buf][((tid >> 2) + 64 * i) * LDK + akq * 4], rb_ok[i] ? rb[i] : zero4);
+      for (int i = 0; i < BPASS; ++i) st4(&Bs[buf][((tid >> 3) + 32 * i) * GLDK + akq * 4], rb_ok[i] ? rb[i] : zero4);
     } else {
-      constexpr int F4_PER_ROW = BN / 4;
-      constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
 #pragma unroll
       for (int i = 0; i < BPASS; ++i)
         st4(&Bs[buf][(tid / F4_PER_ROW + ROWS_PER_PASS * i) * BN + (tid % F4_PER_ROW) * 4], rb_ok[i] ? rb[i] : zero4);
@@ -188,10 +192,10 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // software pipeline: tile k is in LDS, tile k+1 is in flight in registers.  In the middle of
-  // tile k's MFMAs the registers are written to the other LDS stage and immediately re-issued
-  // for tile k+2: global-load latency gets a whole tile of MFMAs, the ds_writes hide under the
-  // second MFMA half, and only a bare barrier is left at the end of the iteration.
+  // software pipeline: tile k is in LDS, tile k+1 is in flight in registers.  Early in tile k
+  // the registers are written to the other LDS stage and immediately re-issued for tile k+2:
+  // global-load latency gets a whole tile of MFMAs, the ds_writes hide under them, and only a
+  // bare barrier is left at the end of the iteration.
   if (nk > 0) {
     load_tile();
     store_tile(0);
@@ -199,41 +203,46 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
   }
   __syncthreads();
 
-  // One K tile.  DoStore/DoLoad are compile-time so that the steady-state loop body is a single
-  // basic block: the compiler is then free to slide the staging instructions (selects, ds_write,
-  // address maths, global loads) in between the MFMAs instead of clumping them.
+  // One K tile (32 deep = two 16-deep halves).  do_store/do_load are compile-time so that the
+  // steady-state loop body is a single basic block the compiler can interleave freely.
   auto k_tile = [&](int kt, auto do_store, auto do_load) {
     const int buf = kt & 1;
     const float* as = As[buf];
     const float* bs = Bs[buf];
-    float4 av[2][MT], bv[2][NT];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int half = 0; half < 2; ++half) {
+      float4 av[2][MT], bv[2][NT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) av[q][mt] = ld4(&as[(wr * WM + mt * 32 + lr) * LDK + q * 8 + h * 4]);
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int q = half * 2 + q2;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        if constexpr (B_KC) {
-          bv[q][nt] = ld4(&bs[(wc * WN + nt * 32 + lr) * LDK + q * 8 + h * 4]);
-        } else {
-          const float* p = &bs[(q * 8 + h * 4) * BN + wc * WN + nt * 32 + lr];
-          bv[q][nt] = make_float4(p[0], p[BN], p[2 * BN], p[3 * BN]);
+        for (int mt = 0; mt < MT; ++mt) av[q2][mt] = ld4(&as[(wr * WM + mt * 32 + lr) * GLDK + q * 8 + h * 4]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (B_KC) {
+            bv[q2][nt] = ld4(&bs[(wc * WN + nt * 32 + lr) * GLDK + q * 8 + h * 4]);
+          } else {
+            const float* p = &bs[(q * 8 + h * 4) * BN + wc * WN + nt * 32 + lr];
+            bv[q2][nt] = make_float4(p[0], p[BN], p[2 * BN], p[3 * BN]);
+          }
         }
       }
-    }
-    if constexpr (decltype(do_store)::value) store_tile(buf ^ 1);
-    if constexpr (decltype(do_load)::value) load_tile();
+      if (half == 0) {
+        if constexpr (decltype(do_store)::value) store_tile(buf ^ 1);
+        if constexpr (decltype(do_load)::value) load_tile();
+      }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+      for (int q2 = 0; q2 < 2; ++q2) {
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const float a = jj == 0 ? av[q][mt].x : jj == 1 ? av[q][mt].y : jj == 2 ? av[q][mt].z : av[q][mt].w;
+          for (int mt = 0; mt < MT; ++mt) {
+            const float a = jj == 0 ? av[q2][mt].x : jj == 1 ? av[q2][mt].y : jj == 2 ? av[q2][mt].z : av[q2][mt].w;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const float b = jj == 0 ? bv[q][nt].x : jj == 1 ? bv[q][nt].y : jj == 2 ? bv[q][nt].z : bv[q][nt].w;
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+              const float b = jj == 0 ? bv[q2][nt].x : jj == 1 ? bv[q2][nt].y : jj == 2 ? bv[q2][nt].z : bv[q2][nt].w;
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
+            }
           }
         }
       }
