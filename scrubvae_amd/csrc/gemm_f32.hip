@@ -340,39 +340,41 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
     b_b[i] = r / g.nj;
     b_jj[i] = (int)(r - b_b[i] * g.nj);
   }
+  bool ra_ok[APASS], rb_ok[BPASS];
+  // branch-free loads (clamped address now, zero-select at the LDS store): conditional loads
+  // make hipcc wait vmcnt(0) after each one, serialising the memory latencies of a tile
   auto load_tile = [&](long long r0) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const long long r = r0 + a_r + AROWS_PER_PASS * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < r_end && a_c < g.Kc) {
-        const int xr = a_jj[i] * g.sx + tbx;
-        const int yr = a_jj[i] * g.sy + tby;
-        if (xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly) v = ld4(g.X + (a_b[i] * g.Lx + xr) * (long long)g.ldX + a_c);
-      }
-      ra[i] = v;
+      const int xr = a_jj[i] * g.sx + tbx;
+      const int yr = a_jj[i] * g.sy + tby;
+      const bool ok = r < r_end && a_c < g.Kc && xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly;
+      ra[i] = ld4(g.X + ((ok ? a_b[i] : 0) * g.Lx + (ok ? xr : 0)) * (long long)g.ldX + (ok ? a_c : 0));
+      ra_ok[i] = ok;
       a_jj[i] += r16; a_b[i] += q16;
       if (a_jj[i] >= g.nj) { a_jj[i] -= g.nj; ++a_b[i]; }
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
       const long long r = r0 + b_r + ROWS_PER_PASS * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < r_end && b_n < g.N) {
-        const int xr = b_jj[i] * g.sx + tbx;
-        const int yr = b_jj[i] * g.sy + tby;
-        if (xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly) v = ld4(g.dY + (b_b[i] * g.Ly + yr) * (long long)g.ldY + b_n);
-      }
-      rb[i] = v;
+      const int xr = b_jj[i] * g.sx + tbx;
+      const int yr = b_jj[i] * g.sy + tby;
+      const bool ok = r < r_end && b_n < g.N && xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly;
+      rb[i] = ld4(g.dY + ((ok ? b_b[i] : 0) * g.Ly + (ok ? yr : 0)) * (long long)g.ldY + (ok ? b_n : 0));
+      rb_ok[i] = ok;
       b_jj[i] += r16; b_b[i] += q16;
       if (b_jj[i] >= g.nj) { b_jj[i] -= g.nj; ++b_b[i]; }
     }
   };
   auto store_tile = [&](int buf) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < APASS; ++i) st4(&As[buf][(a_r + AROWS_PER_PASS * i) * BM + (tid % AF4_PER_ROW) * 4], ra[i]);
+    for (int i = 0; i < APASS; ++i)
+      st4(&As[buf][(a_r + AROWS_PER_PASS * i) * BM + (tid % AF4_PER_ROW) * 4], ra_ok[i] ? ra[i] : zero4);
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) st4(&Bs[buf][(b_r + ROWS_PER_PASS * i) * BN + (tid % F4_PER_ROW) * 4], rb[i]);
+    for (int i = 0; i < BPASS; ++i)
+      st4(&Bs[buf][(b_r + ROWS_PER_PASS * i) * BN + (tid % F4_PER_ROW) * 4], rb_ok[i] ? rb[i] : zero4);
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -449,13 +451,162 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
   }
 }
 
+// ---------------------------------------------------------- tap-fused weight gradient
+// Small-weight layers (few output tiles, very long reductions): one workgroup owns a 64x64
+// (c_in x c_out) tile for up to TG taps at once.  The operand whose rows do not depend on the
+// tap ("shared": dY for a conv, X for a transposed conv) is staged once per 16 reduction rows,
+// the other one once per tap; every tap has its own 32x32 accumulator per wave.  Compared with
+// wgrad_gemm this does TG x the MFMA work per staged shared tile and produces TG x fewer slabs.
+struct WgradFusedArgs {
+  const float* S;   // shared operand   [rows = b*Ls + j][ldS]
+  const float* P;   // per-tap operand  [rows = b*Lp + j*sp + bp[t]][ldP]
+  float* out;       // slab base [nsplit][T][Kc][ldW] (or dw itself when nsplit == 1)
+  long long R, rows_per_split, slab_stride;
+  int nj, Ls, Lp, sp;
+  int bp[SVAE_MAX_TAPS];
+  int T, Kc, N, ldS, ldP, ldW;
+  int ctiles, ntiles, accumulate;
+};
+
+template <int TG, bool P_IS_A>
+__global__ __launch_bounds__(256) void wgrad_fused_kernel(const WgradFusedArgs g) {
+  constexpr int TB = 64;  // tile edge (both ways)
+  __shared__ __attribute__((aligned(16))) float Ps[2][TG][BK * TB];
+  __shared__ __attribute__((aligned(16))) float Ss[2][BK * TB];
+  const int tid = threadIdx.x;
+  const int ct = blockIdx.x / g.ntiles, nt_ = blockIdx.x - ct * g.ntiles;
+  const int c0 = ct * TB, n0 = nt_ * TB;
+  const int t0 = blockIdx.y * TG;
+  const int ntap = (g.T - t0) < TG ? (g.T - t0) : TG;
+  const long long r_begin = (long long)blockIdx.z * g.rows_per_split;
+  long long r_end = r_begin + g.rows_per_split;
+  if (r_end > g.R) r_end = g.R;
+  // the A operand has c_in columns, the B operand c_out columns
+  const int s_col0 = P_IS_A ? n0 : c0, p_col0 = P_IS_A ? c0 : n0;
+  const int s_cols = P_IS_A ? g.N : g.Kc, p_cols = P_IS_A ? g.Kc : g.N;
+
+  const int lrow = tid >> 4, lc4 = (tid & 15) * 4;  // one float4 of a 16 x 64 tile per thread
+  const bool s_ok_col = s_col0 + lc4 < s_cols, p_ok_col = p_col0 + lc4 < p_cols;
+  const int q16 = BK / g.nj, r16 = BK % g.nj;
+  long long rb;
+  int rj;
+  {
+    const long long r = r_begin + lrow;
+    rb = r / g.nj;
+    rj = (int)(r - rb * g.nj);
+  }
+  float4 rs, rp[TG];
+  bool rs_ok, rp_ok[TG];
+  long long next_r = r_begin + lrow;
+  auto load_tile = [&]() {
+    const bool row_ok = next_r < r_end;
+    rs_ok = row_ok && s_ok_col;
+    rs = ld4(g.S + ((rs_ok ? rb : 0) * g.Ls + (rs_ok ? rj : 0)) * (long long)g.ldS + (s_ok_col ? s_col0 + lc4 : 0));
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      if (t < ntap) {
+        const int pr = rj * g.sp + g.bp[t0 + t];
+        const bool ok = row_ok && p_ok_col && pr >= 0 && pr < g.Lp;
+        rp_ok[t] = ok;
+        rp[t] = ld4(g.P + ((ok ? rb : 0) * g.Lp + (ok ? pr : 0)) * (long long)g.ldP + (p_ok_col ? p_col0 + lc4 : 0));
+      }
+    }
+    next_r += BK;
+    rj += r16; rb += q16;
+    if (rj >= g.nj) { rj -= g.nj; ++rb; }
+  };
+  auto store_tile = [&](int buf) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    st4(&Ss[buf][lrow * TB + lc4], rs_ok ? rs : zero4);
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+      if (t < ntap) st4(&Ps[buf][t][lrow * TB + lc4], rp_ok[t] ? rp[t] : zero4);
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 31, h = lane >> 5;
+  f32x16 acc[TG];
+#pragma unroll
+  for (int t = 0; t < TG; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int nk = (int)((r_end - r_begin + BK - 1) / BK);
+  if (nk > 0) {
+    load_tile();
+    store_tile(0);
+    if (nk > 1) load_tile();
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    // shared-operand fragment (8 k values per lane), reused by every tap
+    float sv[8];
+    const int s_lane_col = (P_IS_A ? wc : wr) * 32 + lr;
+    const int p_lane_col = (P_IS_A ? wr : wc) * 32 + lr;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) sv[q * 4 + jj] = Ss[buf][(q * 8 + h * 4 + jj) * TB + s_lane_col];
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    if (kt + 2 < nk) load_tile();
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      if (t < ntap) {
+        float pv[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) pv[q * 4 + jj] = Ps[buf][t][(q * 8 + h * 4 + jj) * TB + p_lane_col];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if constexpr (P_IS_A) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[e], sv[e], acc[t], 0, 0, 0);
+          else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[e], pv[e], acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const int col = n0 + wc * 32 + lr;
+  if (col < g.N) {
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      if (t < ntap) {
+        float* out = g.out + (long long)blockIdx.z * g.slab_stride + (long long)(t0 + t) * g.Kc * g.ldW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = c0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (c < g.Kc) {
+            float* dst = out + (long long)c * g.ldW + col;
+            float v = acc[t][r];
+            if (g.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 // dst[i] (+)= sum_s slab[s][i], fixed order
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dst,
                                                             long long n4, long long stride, int nsplit, int accumulate) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+  // 16 slab loads in flight per thread (the slabs are `stride` apart: every load is its own
+  // latency), summed in slab order -> same bits every run
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 s = accumulate ? ld4(dst + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < nsplit; ++k) {
-      const float4 v = ld4(slab + k * stride + i * 4);
+    int k = 0;
+    for (; k + 16 <= nsplit; k += 16) {
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = ld4(slab + (long long)(k + u) * stride + i * 4);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < nsplit; ++k) {
+      const float4 v = ld4(slab + (long long)k * stride + i * 4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     st4(dst + i * 4, s);
@@ -641,12 +792,30 @@ extern "C" int svae_conv_dgrad(const svae_conv_desc* d, const float* dy, const f
 }
 
 namespace svae {
-struct WgradGeo { int bm, bn, nsplit, nj, ctiles; long long rps, R; };
+struct WgradGeo { int bm, bn, nsplit, nj, ctiles; long long rps, R; int fused, tg, tgroups; };
 
 static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
   WgradGeo w;
   w.nj = d->transposed ? d->l_in : d->l_out;
   w.R = (long long)d->batch * w.nj;
+  w.fused = 0; w.tg = 0; w.tgroups = 0;
+  if (d->tile[2] == 1) {  // tap-fused small-weight kernel: 64x64 tiles, up to TG taps per workgroup
+    w.fused = 1;
+    w.bm = w.bn = 64;
+    w.tg = d->kernel <= 5 ? 5 : 8;
+    w.tgroups = (d->kernel + w.tg - 1) / w.tg;
+    w.ctiles = (d->c_in + 63) / 64;
+    const long long tiles = (long long)w.ctiles * ((d->c_out + 63) / 64) * w.tgroups;
+    const long long slots = 256 * 3;
+    long long want = tiles >= slots ? 1 : slots / tiles;
+    const long long maxs = (w.R + 127) / 128;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    w.rps = (w.R + want - 1) / want;
+    w.rps = ((w.rps + BK - 1) / BK) * BK;
+    w.nsplit = (int)((w.R + w.rps - 1) / w.rps);
+    return w;
+  }
   // tile rows run over the input channels of ONE tap: 64-row tiles when c_in has no 128 multiple
   w.bm = (d->c_in % 128 == 0) ? 128 : 64;
   const int w128 = ((d->c_out + 127) / 128) * 128, w64 = ((d->c_out + 63) / 64) * 64;
@@ -717,17 +886,40 @@ extern "C" int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const fl
   float* slab = (float*)ws;
   if (nsplit > 1) { g.out = slab; g.slab_stride = wsize; g.accumulate = 0; }
   else { g.out = dw; g.slab_stride = 0; g.accumulate = accumulate; }
+  if (wg.fused) {
+    WgradFusedArgs f;
+    memset(&f, 0, sizeof(f));
+    f.R = wg.R; f.rows_per_split = wg.rps; f.nj = wg.nj;
+    f.T = d->kernel; f.Kc = d->c_in; f.N = d->c_out; f.ldW = d->c_out;
+    f.ctiles = wg.ctiles; f.ntiles = (d->c_out + 63) / 64;
+    for (int t = 0; t < d->kernel; ++t) f.bp[t] = t * d->dilation - d->padding;
+    f.sp = d->stride;
+    if (!d->transposed) { f.S = dy; f.Ls = d->l_out; f.ldS = d->ld_out; f.P = x; f.Lp = d->l_in; f.ldP = d->ld_in; }
+    else { f.S = x; f.Ls = d->l_in; f.ldS = d->ld_in; f.P = dy; f.Lp = d->l_out; f.ldP = d->ld_out; }
+    if (nsplit > 1) { f.out = slab; f.slab_stride = wsize; f.accumulate = 0; }
+    else { f.out = dw; f.slab_stride = 0; f.accumulate = accumulate; }
+    dim3 fgrid(f.ctiles * f.ntiles, wg.tgroups, nsplit);
+    if (!d->transposed) {
+      if (wg.tg == 5) hipLaunchKernelGGL((wgrad_fused_kernel<5, true>), fgrid, dim3(256), 0, st, f);
+      else hipLaunchKernelGGL((wgrad_fused_kernel<8, true>), fgrid, dim3(256), 0, st, f);
+    } else {
+      if (wg.tg == 5) hipLaunchKernelGGL((wgrad_fused_kernel<5, false>), fgrid, dim3(256), 0, st, f);
+      else hipLaunchKernelGGL((wgrad_fused_kernel<8, false>), fgrid, dim3(256), 0, st, f);
+    }
+    if (int e = check_launch("wgrad_fused")) return e;
+  } else {
   dim3 grid(d->kernel * g.ctiles, (d->c_out + wg.bn - 1) / wg.bn, nsplit);
   if (wg.bm == 128 && wg.bn == 128) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 128>), grid, dim3(256), 0, st, g);
   else if (wg.bm == 128 && wg.bn == 64) hipLaunchKernelGGL((wgrad_gemm_kernel<128, 64>), grid, dim3(256), 0, st, g);
   else if (wg.bm == 64 && wg.bn == 128) hipLaunchKernelGGL((wgrad_gemm_kernel<64, 128>), grid, dim3(256), 0, st, g);
   else hipLaunchKernelGGL((wgrad_gemm_kernel<64, 64>), grid, dim3(256), 0, st, g);
   if (int e = check_launch("wgrad_gemm")) return e;
+  }
   if (nsplit > 1) {
     const long long n4 = wsize / 4;
-    int blocks = (int)((n4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slab, dw, n4, wsize, nsplit, accumulate);
+    int blocks = (int)((n4 + 63) / 64);  // 64-thread blocks: small weights still spread over many CUs
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(64), 0, st, slab, dw, n4, wsize, nsplit, accumulate);
     if (int e = check_launch("reduce_slabs")) return e;
   }
   if (db) {
@@ -750,7 +942,8 @@ extern "C" int svae_conv_tile(const svae_conv_desc* d, int kind, int* bm, int* b
   SVAE_REQUIRE(bm && bn && kind >= 0 && kind <= 2, SVAE_ERR_ARG, "conv_tile: bad args");
   if (kind == 2) {
     const WgradGeo wg = wgrad_geometry(d);
-    *bm = wg.bm; *bn = wg.bn;
+    *bm = wg.fused ? -wg.tg : wg.bm;  // negative: tap-fused kernel with TG = -bm
+    *bn = wg.bn;
     return SVAE_OK;
   }
   GatherArgs g;

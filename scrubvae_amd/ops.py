@@ -63,6 +63,7 @@ TIMER = None  # set to a LaunchTimer to enable
 AUTOTUNE = True
 AUTOTUNE_MIN_FLOPS = 2e8
 _TILES = (128128, 128064, 64128, 64064)
+_WGRAD_CODES = _TILES + (1,)  # 1 = tap-fused small-weight kernel
 
 
 _KIND_ID = {"fwd": 0, "dgrad": 1, "wgrad": 2}
@@ -111,7 +112,7 @@ class Conv:
         if not AUTOTUNE or self.flops < AUTOTUNE_MIN_FLOPS or torch.cuda.is_current_stream_capturing():
             return
         best, best_t = 0, float("inf")
-        for code in _TILES:
+        for code in (_WGRAD_CODES if kind == "wgrad" else _TILES):
             self.desc.tile[k] = code
             self._ws_bytes = None
             try:
@@ -139,7 +140,8 @@ class Conv:
             bm, bn = C.c_int(), C.c_int()
             check(_lib.lib().svae_conv_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn)), "conv_tile")
             if kind == "wgrad":
-                names[kind] = f"wgrad_gemm_kernel<{bm.value}, {bn.value}>"
+                names[kind] = (f"wgrad_fused_kernel<{-bm.value}, {'false' if self.desc.transposed else 'true'}>" if bm.value < 0
+                               else f"wgrad_gemm_kernel<{bm.value}, {bn.value}>")
             else:
                 names[kind] = f"gather_gemm_kernel<{bm.value}, {bn.value}, {'true' if kind == 'dgrad' else 'false'}>"
         return names[kind]
@@ -152,7 +154,7 @@ class Conv:
         """Workspace for the current tile; before tuning: the maximum over all candidate tiles."""
         if "wgrad" not in self.__dict__.get("_tuned", ()) and AUTOTUNE and self.flops >= AUTOTUNE_MIN_FLOPS:
             keep, need = self.desc.tile[2], 0
-            for code in _TILES:
+            for code in _WGRAD_CODES:
                 self.desc.tile[2] = code
                 need = max(need, int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc))))
             self.desc.tile[2] = keep
@@ -185,7 +187,7 @@ class Conv:
             sdb = torch.empty(self.c_out_p, device=x.device)
             self.desc.tile[2] = 0
             need = 0
-            for code in _TILES:  # scratch workspace large enough for every candidate
+            for code in _WGRAD_CODES:  # scratch workspace large enough for every candidate
                 self.desc.tile[2] = code
                 need = max(need, int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc))))
             self.desc.tile[2] = 0

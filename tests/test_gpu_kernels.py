@@ -328,3 +328,50 @@ def test_small_losses(ops):
     ops.double_softmax_ce_sum(ld_, 16, rows, -0.25, part, dl)
     assert abs(float(part.double().sum()) - float(l)) < 1e-5 * float(l)
     assert relerr(dl.cpu()[:, :2], logits.grad) < 2e-6
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("code", [1, 128128, 64128, 128064, 64064])
+def test_wgrad_kernel_variants(ops, case, code):
+    """Every weight-gradient kernel variant (tile overrides and the tap-fused kernel) gives the
+    same result as torch's conv backward."""
+    B, L, Cin, Cout, k, s, p, tr = case
+    g = torch.Generator().manual_seed(7 + sum(case[:7]))
+    x = torch.randn(B, Cin, L, generator=g, dtype=torch.float64)
+    w = (torch.randn(*((Cin, Cout, k) if tr else (Cout, Cin, k)), generator=g, dtype=torch.float64)).requires_grad_(True)
+    y = (F.conv_transpose1d if tr else F.conv1d)(x, w, None, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    cv = ops.Conv(B, L, Cin, Cout, k, s, p, 1, tr)
+    cv.__dict__["_tuned"] = {"fwd", "dgrad", "wgrad"}
+    cv.desc.tile[2] = code
+    cv._ws_bytes = None
+    xd, dyd = to_nlc(x), to_nlc(dy)
+    ws = torch.empty(cv.wgrad_workspace_bytes() // 4 + 4, device="cuda")
+    dwd = torch.full(cv.weight_shape, float("nan"), device="cuda")
+    cv.wgrad(xd, dyd, dwd, None, ws)
+    dw = ops.conv_weight_from_tio(dwd.cpu(), Cin, Cout, tr)
+    assert relerr(dw, w.grad) < 2e-6 * math.sqrt(B * y.shape[-1]) + 2e-6
+    assert not torch.isnan(dwd).any()
+
+
+@pytest.mark.parametrize("case", CONV_CASES[:8])
+@pytest.mark.parametrize("code", [128128, 64128, 128064, 64064])
+def test_gather_kernel_variants(ops, case, code):
+    B, L, Cin, Cout, k, s, p, tr = case
+    g = torch.Generator().manual_seed(9 + sum(case[:7]))
+    x = torch.randn(B, Cin, L, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(*((Cin, Cout, k) if tr else (Cout, Cin, k)), generator=g, dtype=torch.float64) / math.sqrt(Cin * k)
+    y = (F.conv_transpose1d if tr else F.conv1d)(x, w, None, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    cv = ops.Conv(B, L, Cin, Cout, k, s, p, 1, tr)
+    cv.__dict__["_tuned"] = {"fwd", "dgrad", "wgrad"}
+    cv.desc.tile[0] = cv.desc.tile[1] = code
+    wd = ops.conv_weight_to_tio(w.float(), tr).cuda().contiguous()
+    yd = torch.full((B * cv.l_out, cv.c_out_p), float("nan"), device="cuda")
+    cv.fwd(to_nlc(x.detach()), wd, None, yd)
+    assert relerr(from_nlc(yd, B, cv.l_out, Cout), y.detach()) < 2e-6 * math.sqrt(Cin * k) + 2e-6
+    dxd = torch.full((B * L, cv.c_in_p), float("nan"), device="cuda")
+    cv.dgrad(to_nlc(dy), wd, dxd)
+    assert relerr(from_nlc(dxd, B, L, Cin), x.grad) < 2e-6 * math.sqrt(Cout * k) + 2e-6
