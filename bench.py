@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--window", type=int, default=64)
     ap.add_argument("--full", action="store_true", help="configs[2]: conditional + grad-reversal + adversarial heads")
     ap.add_argument("--local-bn", action="store_true", help="per-rank BatchNorm statistics (no sync-BN collectives)")
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph (single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--timer-kinds", default="fwd,dgrad", help="GEMM kinds bracketed with HIP events (fwd,dgrad,wgrad)")
@@ -120,7 +121,7 @@ def main():
     rank, local, world = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     from scrubvae_amd.data import synthetic
     method, feats, loss = make_cfg(args)
     B = args.batch
@@ -131,7 +132,15 @@ def main():
     opt = FusedAdam(model, lr=1e-4, weight_decay=0.01, decoupled=True)
     model.train()
 
+    graphed = None
+    if args.graph:
+        from scrubvae_amd.train.trainer import GraphedStep
+        graphed = GraphedStep(model, opt, loss, dis, data)
+        args.no_roofline = True  # per-launch events cannot be recorded inside a replay
+
     def step():
+        if graphed is not None:
+            return graphed()
         data_o = model(data)
         bl = get_batch_loss(model, data, data_o, loss, dis)
         bl["total"].backward()
@@ -140,6 +149,7 @@ def main():
         return bl
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -165,10 +175,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.TIMER = None
-    tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    if world > 1:
+    if world > 1:  # MAX over ranks
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tt)
+        dt = float(tt)
     total_loss = float(bl["total"].detach())
 
     if rank == 0:
@@ -182,6 +192,7 @@ def main():
                                     "configs[1] mouse-skeleton rcnn, recon+KL (jpe+root+prior), AdamW") +
                                    f", batch {B}/GPU, window {args.window}, {args.joints} joints, z=32, channels [64,128,256,512,1024]",
                        "batch_per_gpu": B, "global_batch": B * world, "window": args.window, "joints": args.joints,
+                       "launch": "hipGraph replay" if args.graph else "eager launches",
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("+localbn" if args.local_bn else "+syncbn")),
                        "final_total_loss": total_loss},
         }
@@ -201,7 +212,7 @@ def main():
                                        k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                            "avg_us": round(v["ms"] * 1e3 / v["launches"], 2), "launches_per_step": v["launches"]}
                                        for k, v in sorted(probe.summary().items())}}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, method, feats, loss)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -239,6 +239,11 @@ int svae_colsum_batched(const svae_colsum_task* tasks, int n, void* ws, size_t w
 int svae_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step_t, int decoupled,
                    float grad_scale, void* stream);
+/* hipGraph-capturable form: hyper (device, 3 floats) = {lr, lr/(1-beta1^t), 1/sqrt(1-beta2^t)},
+ * refreshed by the host before every replay */
+int svae_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper,
+                       float beta1, float beta2, float eps, float weight_decay, int decoupled,
+                       float grad_scale, void* stream);
 /* sum of squares partials for clip_grad_norm_ (trainer.py:164): part[svae_sumsq_blocks(n)] */
 int svae_sumsq_blocks(long long n);
 int svae_sumsq_partial(const float* x, long long n, float* part, void* stream);

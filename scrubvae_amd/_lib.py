@@ -88,6 +88,7 @@ SIGNATURES = {
     "svae_rot_loss": (I, [P, P, F, P, P, LL, P]),
     "svae_rot_blocks": (I, [LL]),
     "svae_adam_step": (I, [P, P, P, P, LL, F, F, F, F, F, I, I, F, P]),
+    "svae_adam_step_dev": (I, [P, P, P, P, LL, P, F, F, F, F, I, F, P]),
     "svae_sumsq_blocks": (I, [LL]),
     "svae_sumsq_partial": (I, [P, LL, P, P]),
     "svae_reduce_rows": (I, [P, I, I, F, P, I, P]),

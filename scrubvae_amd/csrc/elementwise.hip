@@ -447,6 +447,33 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// hipGraph-safe variant: the step-dependent scalars (lr, lr/bias_correction1, 1/sqrt(bias_correction2))
+// live in device memory and are refreshed by the host before each replay
+__global__ __launch_bounds__(256) void adam_kernel_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long long n, const float* __restrict__ hyper,
+                                                        float b1, float b2, float eps, float wd, int decoupled, float gscale) {
+  const float lr = hyper[0], step_size = hyper[1], inv_bc2_sqrt = hyper[2];
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 pv = ld4(p + i * 4), gv = ld4(g + i * 4), mv = ld4(m + i * 4), vv = ld4(v + i * 4);
+    float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w},
+          vq[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gk = gg[k] * gscale;
+      if (decoupled) pp[k] *= (1.f - lr * wd);
+      else if (wd != 0.f) gk += wd * pp[k];
+      mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+      vq[k] = b2 * vq[k] + (1.f - b2) * gk * gk;
+      const float denom = sqrtf(vq[k]) * inv_bc2_sqrt + eps;
+      pp[k] -= step_size * mm[k] / denom;
+    }
+    st4(p + i * 4, make_float4(pp[0], pp[1], pp[2], pp[3]));
+    st4(m + i * 4, make_float4(mm[0], mm[1], mm[2], mm[3]));
+    st4(v + i * 4, make_float4(vq[0], vq[1], vq[2], vq[3]));
+  }
+}
+
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
   __shared__ float red4[4];
   float s = 0.f;
@@ -688,6 +715,14 @@ extern "C" int svae_adam_step(float* p, const float* g, float* m, float* v, long
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2, eps,
                      weight_decay, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), decoupled, grad_scale);
   return check_launch("adam_step");
+}
+
+extern "C" int svae_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1,
+                                  float beta2, float eps, float weight_decay, int decoupled, float grad_scale, void* stream) {
+  SVAE_REQUIRE(p && g && m && v && hyper && n > 0 && n % 4 == 0, SVAE_ERR_ARG, "adam_step_dev: bad args");
+  hipLaunchKernelGGL(adam_kernel_dev, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, n, hyper, beta1, beta2,
+                     eps, weight_decay, decoupled, grad_scale);
+  return check_launch("adam_step_dev");
 }
 
 extern "C" int svae_sumsq_blocks(long long n) { return grid_for(n / 4, 256, 1024); }

@@ -400,6 +400,11 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_t, decoupled
                                     int(decoupled), grad_scale, _stream()), "adam_step")
 
 
+def adam_step_dev(p, g, m, v, hyper, beta1, beta2, eps, weight_decay, decoupled, grad_scale=1.0):
+    check(_lib.lib().svae_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), beta1, beta2, eps, weight_decay,
+                                        int(decoupled), grad_scale, _stream()), "adam_step_dev")
+
+
 def sumsq_blocks(n):
     return int(_lib.lib().svae_sumsq_blocks(n))
 
