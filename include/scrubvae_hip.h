@@ -60,7 +60,8 @@ typedef struct {
   int transposed;    /* 0 = nn.Conv1d, 1 = nn.ConvTranspose1d; Linear: kernel=1,l=1 */
   /* tuning overrides (results are bit-identical for every tile: the per-output summation
    * order over K does not depend on it).  tile[kind] = BM*1000+BN with BM,BN in {64,128}, or
-   * 0 for the built-in heuristic; kind 0 fwd, 1 dgrad, 2 wgrad.  tile[2] = 1 selects the tap-fused
+   * 0 for the built-in heuristic; kind 0 fwd, 1 dgrad, 2 wgrad.  Adding 1000000 (fwd/dgrad) selects
+   * the LDS-DMA staging variant (global_load_lds, XOR-swizzled LDS image).  tile[2] = 1 selects the tap-fused
    * small-weight gradient kernel (64x64 tiles, all taps of a tile in one workgroup). */
   int tile[3];
 } svae_conv_desc;

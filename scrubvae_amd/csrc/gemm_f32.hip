@@ -279,6 +279,217 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
   }
 }
 
+// ------------------------------------------------------------------ LDS-DMA variant
+// Same math and tiles as gather_gemm_kernel, but both operands go global -> LDS directly
+// (global_load_lds_dwordx4): no staging VGPRs, no ds_write, no zero-select VALU.  The LDS image
+// of a K-contiguous tile is linear [row][32] (one 128-byte row = 8 chunks of 16 B; a wave
+// instruction fills 8 rows); bank conflicts of the ds_read_b128 fragment reads are removed by an
+// XOR swizzle applied on the per-lane SOURCE address (chunk' = chunk ^ ((row>>1)&7)) and again on
+// the read.  Rows that fall into conv padding / past M / past Kc read from a zero page.
+__device__ __attribute__((aligned(16))) float g_zero_page[64];
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+
+template <int BM, int BN, bool B_KC>
+__global__ __launch_bounds__(256) void gather_gemm_dma_kernel(const GatherArgs g) {
+  constexpr int WM = BM / 2, MT = WM / 32, WN = BN / 2, NT = WN / 32;
+  constexpr int A_ELEMS = BM * GBK;
+  constexpr int B_ELEMS = BN * GBK;
+  constexpr int APASS = BM / 32;                 // wave instructions per wave for A (8 rows each)
+  constexpr int BPASS = B_KC ? BN / 32 : BN / 32;  // KC: 8 rows of 128 B; KN: 1 KiB = 256/BN k-rows
+  // ONE shared array (a second __shared__ object next to an LDS-DMA target makes hipcc drain vmcnt early)
+  __shared__ __attribute__((aligned(16))) float smem[2 * A_ELEMS + 2 * B_ELEMS + 2 * BM];
+  float* const As0 = smem;
+  float* const Bs0 = smem + 2 * A_ELEMS;
+  long long* const rowoff = reinterpret_cast<long long*>(smem + 2 * A_ELEMS + 2 * B_ELEMS);
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  int bx = blockIdx.x, phase = 0;
+  if (bx >= g.blocks_m[0]) { phase = 1; bx -= g.blocks_m[0]; }
+  const long long m0 = (long long)bx * BM;
+  const int n0 = blockIdx.y * BN;
+  const long long Mp = g.M[phase];
+  const int nj = g.nj[phase];
+  const int ntaps = g.ntaps[phase];
+  const int* __restrict__ tap_base = g.base[phase];
+  const int* __restrict__ tap_w = g.widx[phase];
+
+  // ---- A: lane -> (row, LDS chunk position); the logical chunk it fetches is swizzled
+  const int a_rl = lane >> 3, a_pos = lane & 7;
+  long long a_off[APASS];
+  int a_j[APASS], a_chunk[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int row = (i * 4 + wave) * 8 + a_rl;
+    const long long m = m0 + row;
+    a_chunk[i] = a_pos ^ ((row >> 1) & 7);
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      a_off[i] = b * (long long)g.Lin * g.ldA;
+      a_j[i] = j * g.sj;
+    } else {
+      a_off[i] = 0;
+      a_j[i] = -(1 << 28);
+    }
+  }
+  if (tid < BM) {
+    const long long m = m0 + tid;
+    long long off = -1;
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      off = (b * g.Lout + (phase + g.n_phase * j)) * (long long)g.ldC;
+    }
+    rowoff[tid] = off;
+  }
+  // ---- B lane mapping
+  int b_row[BPASS], b_chunk[BPASS];  // KC: (n row, logical k chunk); KN: (k row, n float4 index)
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    if constexpr (B_KC) {
+      const int row = (i * 4 + wave) * 8 + (lane >> 3);
+      b_row[i] = row;
+      b_chunk[i] = (lane & 7) ^ ((row >> 1) & 7);
+    } else {
+      constexpr int F4 = BN / 4;            // float4 per k-row
+      constexpr int RPI = 64 / F4;          // k-rows per wave instruction (2 for BN=128, 4 for BN=64)
+      b_row[i] = (i * 4 + wave) * RPI + lane / F4;
+      b_chunk[i] = lane % F4;
+    }
+  }
+
+  const int tiles_per_tap = (g.Kc + GBK - 1) / GBK;
+  const int nk = ntaps * tiles_per_tap;
+  int nx_c0 = 0, nx_ti = 0;
+  int nx_tb = ntaps > 0 ? tap_base[0] : 0;
+  long long nx_woff = ntaps > 0 ? (long long)tap_w[0] * g.w_tap_stride : 0;
+  const float* const zp = g_zero_page;
+
+  auto issue_tile = [&](int buf) {
+    const int c0 = nx_c0;
+    const int tb = nx_tb;
+    const float* wt = g.W + nx_woff;
+    {
+      nx_c0 += GBK;
+      const bool wrap = nx_c0 >= g.Kc;
+      nx_c0 = wrap ? 0 : nx_c0;
+      nx_ti += wrap ? 1 : 0;
+      const int tic = nx_ti < ntaps ? nx_ti : ntaps - 1;
+      nx_tb = tap_base[tic];
+      nx_woff = (long long)tap_w[tic] * g.w_tap_stride;
+    }
+    float* as = As0 + buf * A_ELEMS;
+    float* bs = Bs0 + buf * B_ELEMS;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int li = a_j[i] + tb;
+      const int c = c0 + a_chunk[i] * 4;
+      const bool ok = li >= 0 && li < g.Lin && c < g.Kc;
+      const float* src = ok ? g.A + a_off[i] + (long long)li * g.ldA + c : zp;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(as + (i * 4 + wave) * 8 * GBK), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      if constexpr (B_KC) {
+        const int n = n0 + b_row[i];
+        const int c = c0 + b_chunk[i] * 4;
+        const bool ok = n < g.N && c < g.Kc;
+        const float* src = ok ? wt + (long long)n * g.ldW + c : zp;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(bs + (i * 4 + wave) * 8 * GBK), 16, 0, 0);
+      } else {
+        const int k = c0 + b_row[i];
+        const int n = n0 + b_chunk[i] * 4;
+        const bool ok = k < g.Kc && n < g.N;
+        const float* src = ok ? wt + (long long)k * g.ldW + n : zp;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(bs + (i * 4 + wave) * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 31, h = lane >> 5;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) issue_tile(0);
+  __syncthreads();  // (emits vmcnt(0) for the DMA in flight)
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) issue_tile(buf ^ 1);  // the other stage is free since the last barrier
+    const float* as = As0 + buf * A_ELEMS;
+    const float* bs = Bs0 + buf * B_ELEMS;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float4 av[2][MT], bv[2][NT];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int q = half * 2 + q2;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int row = wr * WM + mt * 32 + lr;
+          av[q2][mt] = ld4(&as[row * GBK + (((q * 2 + h) ^ ((row >> 1) & 7)) << 2)]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (B_KC) {
+            const int row = wc * WN + nt * 32 + lr;
+            bv[q2][nt] = ld4(&bs[row * GBK + (((q * 2 + h) ^ ((row >> 1) & 7)) << 2)]);
+          } else {
+            const float* p = &bs[(q * 8 + h * 4) * BN + wc * WN + nt * 32 + lr];
+            bv[q2][nt] = make_float4(p[0], p[BN], p[2 * BN], p[3 * BN]);
+          }
+        }
+      }
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float a = jj == 0 ? av[q2][mt].x : jj == 1 ? av[q2][mt].y : jj == 2 ? av[q2][mt].z : av[q2][mt].w;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const float b = jj == 0 ? bv[q2][nt].x : jj == 1 ? bv[q2][nt].y : jj == 2 ? bv[q2][nt].z : bv[q2][nt].w;
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + wc * WN + nt * 32 + lr;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long off = rowoff[row];
+        if (off >= 0) {
+          float* dst = g.C + off + col;
+          float v = acc[mt][nt][r] + bv;
+          if (g.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------- weight grad
 struct WgradArgs {
   const float* X;
@@ -293,18 +504,20 @@ struct WgradArgs {
   int accumulate;
 };
 
+constexpr int WBK = 16;  // reduction rows per LDS stage of the weight-gradient kernel (32 measured 4 % slower)
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
   constexpr int WM = BM / 2;
   constexpr int MT = WM / 32;
-  constexpr int APASS = BM / 64;
+  constexpr int APASS = BM * WBK / 1024;
   constexpr int AF4_PER_ROW = BM / 4;
   constexpr int AROWS_PER_PASS = 256 / AF4_PER_ROW;
   constexpr int WN = BN / 2;
   constexpr int NT = WN / 32;
-  constexpr int BPASS = BN / 64;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+  constexpr int BPASS = BN * WBK / 1024;
+  __shared__ __attribute__((aligned(16))) float As[2][WBK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WBK * BN];
 
   const int tid = threadIdx.x;
   const int ti = blockIdx.x / g.ctiles;
@@ -323,48 +536,60 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
   const int b_r = tid / F4_PER_ROW;
 
   float4 ra[APASS], rb[BPASS];
-  // reduction rows advance by BK per tile: (batch, position) of each staged row is kept
-  // incrementally (no division in the loop)
-  const int q16 = BK / g.nj, r16 = BK % g.nj;
-  long long a_b[APASS], b_b[BPASS];
+  // Reduction rows advance by BK per tile.  Everything a staged row needs -- its X / dY row
+  // pointers and the two in-range tests -- is advanced with adds only (no division, no 64-bit
+  // multiply in the loop: the weight-gradient kernel was VALU-issue heavy, ~9 VALU per MFMA).
+  const int q16 = WBK / g.nj, r16 = WBK % g.nj;
+  const long long x_step = ((long long)q16 * g.Lx + (long long)r16 * g.sx) * g.ldX;   // +WBK rows, no wrap
+  const long long x_wrap = ((long long)g.Lx - (long long)g.nj * g.sx) * g.ldX;         // j wrapped into next sample
+  const long long y_step = ((long long)q16 * g.Ly + (long long)r16 * g.sy) * g.ldY;
+  const long long y_wrap = ((long long)g.Ly - (long long)g.nj * g.sy) * g.ldY;
+  const float* a_ptr[APASS];
+  const float* b_ptr[BPASS];
   int a_jj[APASS], b_jj[BPASS];
+  long long a_left[APASS], b_left[BPASS];  // rows left before r_end (row valid iff > 0)
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
     const long long r = r_begin + a_r + AROWS_PER_PASS * i;
-    a_b[i] = r / g.nj;
-    a_jj[i] = (int)(r - a_b[i] * g.nj);
+    const long long b = r / g.nj;
+    a_jj[i] = (int)(r - b * g.nj);
+    a_ptr[i] = g.X + (b * g.Lx + (long long)a_jj[i] * g.sx + tbx) * (long long)g.ldX + (a_c < g.Kc ? a_c : 0);
+    a_left[i] = r_end - r;
   }
 #pragma unroll
   for (int i = 0; i < BPASS; ++i) {
     const long long r = r_begin + b_r + ROWS_PER_PASS * i;
-    b_b[i] = r / g.nj;
-    b_jj[i] = (int)(r - b_b[i] * g.nj);
+    const long long b = r / g.nj;
+    b_jj[i] = (int)(r - b * g.nj);
+    b_ptr[i] = g.dY + (b * g.Ly + (long long)b_jj[i] * g.sy + tby) * (long long)g.ldY + (b_n < g.N ? b_n : 0);
+    b_left[i] = r_end - r;
   }
+  const bool a_col_ok = a_c < g.Kc, b_col_ok = b_n < g.N;
   bool ra_ok[APASS], rb_ok[BPASS];
   // branch-free loads (clamped address now, zero-select at the LDS store): conditional loads
   // make hipcc wait vmcnt(0) after each one, serialising the memory latencies of a tile
-  auto load_tile = [&](long long r0) {
+  auto load_tile = [&](long long) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      const long long r = r0 + a_r + AROWS_PER_PASS * i;
-      const int xr = a_jj[i] * g.sx + tbx;
-      const int yr = a_jj[i] * g.sy + tby;
-      const bool ok = r < r_end && a_c < g.Kc && xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly;
-      ra[i] = ld4(g.X + ((ok ? a_b[i] : 0) * g.Lx + (ok ? xr : 0)) * (long long)g.ldX + (ok ? a_c : 0));
+      const int xr = a_jj[i] * g.sx + tbx, yr = a_jj[i] * g.sy + tby;
+      const bool ok = a_left[i] > 0 && a_col_ok && xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly;
+      ra[i] = ld4(ok ? a_ptr[i] : g.X);
       ra_ok[i] = ok;
-      a_jj[i] += r16; a_b[i] += q16;
-      if (a_jj[i] >= g.nj) { a_jj[i] -= g.nj; ++a_b[i]; }
+      a_jj[i] += r16;
+      a_ptr[i] += x_step;
+      a_left[i] -= WBK;
+      if (a_jj[i] >= g.nj) { a_jj[i] -= g.nj; a_ptr[i] += x_wrap; }
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
-      const long long r = r0 + b_r + ROWS_PER_PASS * i;
-      const int xr = b_jj[i] * g.sx + tbx;
-      const int yr = b_jj[i] * g.sy + tby;
-      const bool ok = r < r_end && b_n < g.N && xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly;
-      rb[i] = ld4(g.dY + ((ok ? b_b[i] : 0) * g.Ly + (ok ? yr : 0)) * (long long)g.ldY + (ok ? b_n : 0));
+      const int xr = b_jj[i] * g.sx + tbx, yr = b_jj[i] * g.sy + tby;
+      const bool ok = b_left[i] > 0 && b_col_ok && xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly;
+      rb[i] = ld4(ok ? b_ptr[i] : g.dY);
       rb_ok[i] = ok;
-      b_jj[i] += r16; b_b[i] += q16;
-      if (b_jj[i] >= g.nj) { b_jj[i] -= g.nj; ++b_b[i]; }
+      b_jj[i] += r16;
+      b_ptr[i] += y_step;
+      b_left[i] -= WBK;
+      if (b_jj[i] >= g.nj) { b_jj[i] -= g.nj; b_ptr[i] += y_wrap; }
     }
   };
   auto store_tile = [&](int buf) {
@@ -389,43 +614,43 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (int)((r_end - r_begin + BK - 1) / BK);
+  const int nk = (int)((r_end - r_begin + WBK - 1) / WBK);
   if (nk > 0) {
     load_tile(r_begin);
     store_tile(0);
-    if (nk > 1) load_tile(r_begin + BK);
+    if (nk > 1) load_tile(r_begin + WBK);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     const float* as = As[buf];
     const float* bs = Bs[buf];
-    float av[2][MT][4], bv[2][NT][4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int half = 0; half < WBK / 16; ++half) {
+      float av[2][MT][4], bv[2][NT][4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
+      for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[q][mt][jj] = as[(q * 8 + h * 4 + jj) * BM + wr * WM + mt * 32 + lr];
+        for (int jj = 0; jj < 4; ++jj) {
+          const int kk = half * 16 + q * 8 + h * 4 + jj;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[q][nt][jj] = bs[(q * 8 + h * 4 + jj) * BN + wc * WN + nt * 32 + lr];
-      }
-    __builtin_amdgcn_sched_barrier(0);
+          for (int mt = 0; mt < MT; ++mt) av[q][mt][jj] = as[kk * BM + wr * WM + mt * 32 + lr];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][mt][jj], bv[q][nt][jj], acc[mt][nt], 0, 0, 0);
-      if (q == 0) {  // mid-tile: registers -> other LDS stage, then re-issue them for tile k+2
-        __builtin_amdgcn_sched_barrier(0);
+          for (int nt = 0; nt < NT; ++nt) bv[q][nt][jj] = bs[kk * BN + wc * WN + nt * 32 + lr];
+        }
+      if (half == 0) {  // mid-tile: registers -> other LDS stage, then re-issue them for tile k+2
         if (kt + 1 < nk) store_tile(buf ^ 1);
-        if (kt + 2 < nk) load_tile(r_begin + (long long)(kt + 2) * BK);
-        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) load_tile(r_begin + (long long)(kt + 2) * WBK);
       }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][mt][jj], bv[q][nt][jj], acc[mt][nt], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -705,7 +930,7 @@ static void build_plan(GatherArgs& g, const svae_conv_desc* d, bool strided, int
 // ---- tile selection.  Per-block work is MFMA-bound and co-resident blocks hide each other's
 // barrier / LDS-fill stalls, so prefer the largest tile that still gives >= 2 blocks per CU;
 // below that, more (smaller) blocks win.  Scores are relative throughput estimates.
-struct Tile { int bm, bn; };
+struct Tile { int bm, bn; int dma = 0; };
 
 static double tile_score(long long M0, long long M1, int N, int bm, int bn) {
   const long long bmk = (M0 + bm - 1) / bm + (M1 + bm - 1) / bm;
@@ -734,6 +959,8 @@ static Tile pick_tile(long long M0, long long M1, int N) {
 
 static bool decode_tile(int code, Tile& t) {
   if (code <= 0) return false;
+  t.dma = code >= 1000000 ? 1 : 0;  // 1BBBNNN: LDS-DMA staging variant of the gather kernel
+  code %= 1000000;
   t.bm = code / 1000;
   t.bn = code % 1000;
   return (t.bm == 64 || t.bm == 128) && (t.bn == 64 || t.bn == 128);
@@ -747,6 +974,13 @@ static int launch_gather_auto(GatherArgs& g, hipStream_t st, int override_code) 
   const int bm = g.blocks_m[0] + g.blocks_m[1];
   if (bm == 0) return SVAE_OK;
   dim3 grid(bm, (g.N + t.bn - 1) / t.bn);
+  if (t.dma) {
+    if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gather_gemm_dma_kernel<128, 128, B_KC>), grid, dim3(256), 0, st, g);
+    else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((gather_gemm_dma_kernel<128, 64, B_KC>), grid, dim3(256), 0, st, g);
+    else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((gather_gemm_dma_kernel<64, 128, B_KC>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gather_gemm_dma_kernel<64, 64, B_KC>), grid, dim3(256), 0, st, g);
+    return check_launch("gather_gemm_dma");
+  }
   if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, B_KC>), grid, dim3(256), 0, st, g);
   else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((gather_gemm_kernel<128, 64, B_KC>), grid, dim3(256), 0, st, g);
   else if (t.bm == 64 && t.bn == 128) hipLaunchKernelGGL((gather_gemm_kernel<64, 128, B_KC>), grid, dim3(256), 0, st, g);
@@ -840,7 +1074,7 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
   if (want < 1) want = 1;
   if (want > 512) want = 512;
   w.rps = (w.R + want - 1) / want;
-  w.rps = ((w.rps + BK - 1) / BK) * BK;
+  w.rps = ((w.rps + WBK - 1) / WBK) * WBK;
   w.nsplit = (int)((w.R + w.rps - 1) / w.rps);
   return w;
 }
@@ -952,6 +1186,7 @@ extern "C" int svae_conv_tile(const svae_conv_desc* d, int kind, int* bm, int* b
   else { g.N = d->c_in; build_plan(g, d, d->transposed != 0, d->l_in, d->l_out); }
   Tile t;
   if (!decode_tile(d->tile[kind], t)) t = pick_tile(g.M[0], g.M[1], g.N);
-  *bm = t.bm; *bn = t.bn;
+  *bm = t.dma ? t.bm + 1000 : t.bm;  // +1000: LDS-DMA staging variant
+  *bn = t.bn;
   return SVAE_OK;
 }

@@ -63,6 +63,7 @@ TIMER = None  # set to a LaunchTimer to enable
 AUTOTUNE = True
 AUTOTUNE_MIN_FLOPS = 2e8
 _TILES = (128128, 128064, 64128, 64064)
+_GATHER_CODES = _TILES + tuple(1000000 + c for c in _TILES)  # 1BBBNNN: LDS-DMA staging variant
 _WGRAD_CODES = _TILES + (1,)  # 1 = tap-fused small-weight kernel
 
 
@@ -112,7 +113,7 @@ class Conv:
         if not AUTOTUNE or self.flops < AUTOTUNE_MIN_FLOPS or torch.cuda.is_current_stream_capturing():
             return
         best, best_t = 0, float("inf")
-        for code in (_WGRAD_CODES if kind == "wgrad" else _TILES):
+        for code in (_WGRAD_CODES if kind == "wgrad" else _GATHER_CODES):
             self.desc.tile[k] = code
             self._ws_bytes = None
             try:
@@ -143,7 +144,8 @@ class Conv:
                 names[kind] = (f"wgrad_fused_kernel<{-bm.value}, {'false' if self.desc.transposed else 'true'}>" if bm.value < 0
                                else f"wgrad_gemm_kernel<{bm.value}, {bn.value}>")
             else:
-                names[kind] = f"gather_gemm_kernel<{bm.value}, {bn.value}, {'true' if kind == 'dgrad' else 'false'}>"
+                kn = "gather_gemm_dma_kernel" if bm.value > 1000 else "gather_gemm_kernel"
+                names[kind] = f"{kn}<{bm.value % 1000}, {bn.value}, {'true' if kind == 'dgrad' else 'false'}>"
         return names[kind]
 
     @property

@@ -355,8 +355,8 @@ def test_wgrad_kernel_variants(ops, case, code):
     assert not torch.isnan(dwd).any()
 
 
-@pytest.mark.parametrize("case", CONV_CASES[:8])
-@pytest.mark.parametrize("code", [128128, 64128, 128064, 64064])
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("code", [128128, 64128, 128064, 64064, 1128128, 1064128, 1128064, 1064064])
 def test_gather_kernel_variants(ops, case, code):
     B, L, Cin, Cout, k, s, p, tr = case
     g = torch.Generator().manual_seed(9 + sum(case[:7]))
