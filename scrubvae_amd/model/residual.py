@@ -182,6 +182,9 @@ class ResVAE(nn.Module):
         # only valid after get_batch_loss (which runs the fused tail once).  Off by default.
         self.defer_tail = False
         self._tail_done = True
+        # weight-gradient GEMMs on a second stream, concurrent with the data-gradient chain
+        self.overlap_wgrad = True
+        self._sides, self._side_dirty, self._events, self._event_i = [], set(), [], 0
         self._ws = {}
         self._convs = {}
         self._runners = {}
@@ -296,10 +299,50 @@ class ResVAE(nn.Module):
         return t
 
     def _wgrad(self, cv, x, dy, p, acc):
-        """Weight gradient now; the bias gradient (column sums of dy) is queued and reduced with
-        all the others in two launches at the end of the reverse schedule."""
-        cv.wgrad(x, dy, p.weight.grad, None, self._wgrad_ws(cv), accumulate=acc)
+        """Weight gradient; the bias gradient (column sums of dy) is queued and reduced with all
+        the others in two launches at the end of the reverse schedule.
+
+        Weight gradients are off the critical path of the reverse schedule (nothing downstream
+        reads them), so they go to a second HIP stream: they fill the CUs that the
+        data-gradient / BatchNorm chain leaves idle (single-wave grids, kernel tails).  The side
+        stream is forked from the main stream after `dy` is produced and joined before anything
+        consumes the gradients (_join_side)."""
+        self._fork(lambda: cv.wgrad(x, dy, p.weight.grad, None, self._wgrad_ws(cv), accumulate=acc), k=0)
         self._db_batch.add(dy, cv.batch * cv.l_out, cv.c_out_p, cv.desc.ld_out, p.bias.grad)
+
+    def _side_stream(self, k=0):
+        while len(self._sides) <= k:
+            self._sides.append(torch.cuda.Stream(device=self.device))
+        return self._sides[k]
+
+    def _event(self):
+        """Round-robin pool of events (an event may be re-recorded once its waiters were enqueued)."""
+        if len(self._events) < 64:
+            self._events.append(torch.cuda.Event())
+            return self._events[-1]
+        self._event_i = (self._event_i + 1) % 64
+        return self._events[self._event_i]
+
+    def _fork(self, fn, k=1):
+        """Run fn() on side stream k, ordered after everything queued on the main stream so far.
+        Stream 0 carries the weight gradients, stream 1 the skip branches."""
+        if not self.overlap_wgrad:
+            return fn()
+        main = torch.cuda.current_stream()
+        side = self._side_stream(k)
+        ev = self._event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            fn()
+        self._side_dirty.add(k)
+
+    def _join_side(self, k=None):
+        """Make the main stream wait for side stream k (None: all of them)."""
+        for kk in (list(self._side_dirty) if k is None else [k]):
+            if kk in self._side_dirty:
+                torch.cuda.current_stream().wait_stream(self._sides[kk])
+                self._side_dirty.discard(kk)
 
     def _colsum_ws(self, nbytes):
         n = nbytes // 4 + 16
@@ -415,14 +458,18 @@ class ResVAE(nn.Module):
             conv0, bn1, act1, conv3 = blk.residual
             cv0 = self._conv(t + ".c0", conv0, B, L)
             Lo = cv0.l_out
+            cv3 = self._conv(t + ".c3", conv3, B, Lo)
+            s = self._buf(t + ".s", (B * Lo, cv3.c_out_p))
+            # the skip branch only needs `a`: it runs on the side stream, concurrently with the
+            # residual branch's conv -> BN-stats -> BN+PReLU chain; conv3 then accumulates onto it
+            cvs = self._conv(t + ".sk", blk.skip, B, L)
+            self._fork(lambda: cvs.fwd(a, blk.skip.weight, blk.skip.bias, s))
             r0 = self._buf(t + ".r0", (B * Lo, cv0.c_out_p))
             cv0.fwd(a, conv0.weight, conv0.bias, r0)
             r0a = self._buf(t + ".r0a", (B * Lo, cv0.c_out_p))
             self._bn_act(t + ".bn1", r0, bn1, act1, B * Lo, r0a)
-            cv3 = self._conv(t + ".c3", conv3, B, Lo)
-            s = self._buf(t + ".s", (B * Lo, cv3.c_out_p))
-            cv3.fwd(r0a, conv3.weight, conv3.bias, s)
-            self._conv(t + ".sk", blk.skip, B, L).fwd(a, blk.skip.weight, blk.skip.bias, s, accumulate=True)
+            self._join_side(1)
+            cv3.fwd(r0a, conv3.weight, conv3.bias, s, accumulate=True)
             a2 = self._buf(t + ".a", (B * Lo, cv3.c_out_p))
             self._bn_act(t + ".bn2", s, blk.add[0], blk.add[1], B * Lo, a2)
             a, L = a2, Lo
@@ -477,21 +524,26 @@ class ResVAE(nn.Module):
             t = f"dec.{j}"
             ct1, bn1, act1, ct2 = blk.residual
             cv1 = self._conv(t + ".t1", ct1, B, L)
-            t0 = self._buf(t + ".t0", (B * L, cv1.c_out_p))
-            cv1.fwd(d, ct1.weight, ct1.bias, t0)
-            t0a = self._buf(t + ".t0a", (B * L, cv1.c_out_p))
-            self._bn_act(t + ".bn1", t0, bn1, act1, B * L, t0a)
             cv2 = self._conv(t + ".t2", ct2, B, L)
             Lo = cv2.l_out
             s = self._buf(t + ".s", (B * Lo, cv2.c_out_p))
-            cv2.fwd(t0a, ct2.weight, ct2.bias, s)
             up = self._buf(t + ".up", (B * 2 * L, cv1.c_in_p))
-            ops.upsample2_fwd(d, up, B, L, cv1.c_in_p, cv1.c_in_p)
             sk = blk.skip[1]
             cvs = self._conv(t + ".sk", sk, B, 2 * L)
             if cvs.l_out != Lo:
                 raise ValueError("skip / residual length mismatch")
-            cvs.fwd(up, sk.weight, sk.bias, s, accumulate=True)
+
+            def skip_branch(d=d, up=up, cvs=cvs, sk=sk, s=s, L=L, cin=cv1.c_in_p):
+                ops.upsample2_fwd(d, up, B, L, cin, cin)
+                cvs.fwd(up, sk.weight, sk.bias, s)
+
+            self._fork(skip_branch)  # upsample + skip conv on the side stream
+            t0 = self._buf(t + ".t0", (B * L, cv1.c_out_p))
+            cv1.fwd(d, ct1.weight, ct1.bias, t0)
+            t0a = self._buf(t + ".t0a", (B * L, cv1.c_out_p))
+            self._bn_act(t + ".bn1", t0, bn1, act1, B * L, t0a)
+            self._join_side(1)
+            cv2.fwd(t0a, ct2.weight, ct2.bias, s, accumulate=True)
             d2 = self._buf(t + ".a", (B * Lo, cv2.c_out_p))
             self._bn_act(t + ".bn2", s, blk.add[0], blk.add[1], B * Lo, d2)
             d, L = d2, Lo
@@ -661,15 +713,20 @@ class ResVAE(nn.Module):
             self._wgrad(cvs, up, g_s, sk, acc)
             self._wgrad(cv2, t0a, g_s, ct2, acc)
             g_up = self._buf("g." + t + ".up", (B * 2 * L, cv1.c_in_p))
-            cvs.dgrad(g_s, sk.weight, g_up)
             g_d = self._buf("g." + t + ".in", (B * L, cv1.c_in_p))
-            ops.upsample2_bwd(g_up, g_d, B, L, cv1.c_in_p, cv1.c_in_p)
+
+            def skip_bwd(cvs=cvs, sk=sk, g_s=g_s, g_up=g_up, g_d=g_d, L=L, cin=cv1.c_in_p):
+                cvs.dgrad(g_s, sk.weight, g_up)
+                ops.upsample2_bwd(g_up, g_d, B, L, cin, cin)
+
+            self._fork(skip_bwd, k=1)  # skip branch concurrently with the residual branch below
             g_t0a = self._buf("g." + t + ".t0a", (B * L, cv1.c_out_p))
             cv2.dgrad(g_s, ct2.weight, g_t0a)
             t0 = self._buf(t + ".t0", (B * L, cv1.c_out_p))
             g_t0 = self._buf("g." + t + ".t0", (B * L, cv1.c_out_p))
             self._bn_act_bwd(t + ".bn1", g_t0a, t0, bn1, act1, B * L, g_t0, acc)
             self._wgrad(cv1, d_in, g_t0, ct1, acc)
+            self._join_side(1)
             cv1.dgrad(g_t0, ct1.weight, g_d, accumulate=True)
             g = g_d
         # ---- fc_in
@@ -684,6 +741,7 @@ class ResVAE(nn.Module):
         # overlaps the encoder's reverse schedule (xGMI: few large transfers, not many small ones)
         dec_work = None
         if self.world_size > 1:
+            self._join_side()
             self._db_batch.flush(self._colsum_ws, accumulate=acc)
             lo, hi = self._dec_span
             dec_work = self._allreduce(self.flat_grads[lo:hi], async_op=True)
@@ -725,14 +783,15 @@ class ResVAE(nn.Module):
             r0a = self._buf(t + ".r0a", (B * Lo, cv0.c_out_p))
             self._wgrad(cvs, a_in, g_s, blk.skip, acc)
             self._wgrad(cv3, r0a, g_s, conv3, acc)
+            g_a = self._buf("g." + t + ".in", (B * L, cv0.c_in_p))
+            self._fork(lambda cvs=cvs, g_s=g_s, g_a=g_a, w=blk.skip.weight: cvs.dgrad(g_s, w, g_a), k=1)
             g_r0a = self._buf("g." + t + ".r0a", (B * Lo, cv0.c_out_p))
             cv3.dgrad(g_s, conv3.weight, g_r0a)
             r0 = self._buf(t + ".r0", (B * Lo, cv0.c_out_p))
             g_r0 = self._buf("g." + t + ".r0", (B * Lo, cv0.c_out_p))
             self._bn_act_bwd(t + ".bn1", g_r0a, r0, bn1, act1, B * Lo, g_r0, acc)
             self._wgrad(cv0, a_in, g_r0, conv0, acc)
-            g_a = self._buf("g." + t + ".in", (B * L, cv0.c_in_p))
-            cvs.dgrad(g_s, blk.skip.weight, g_a)
+            self._join_side(1)
             cv0.dgrad(g_r0, conv0.weight, g_a, accumulate=True)
             g = g_a
         # ---- conv_in (bare PReLU in front)
@@ -748,6 +807,7 @@ class ResVAE(nn.Module):
         x_in = self._buf("x_in", (rows, pad16(self.in_channels)))
         cvi = self._conv("enc.conv_in", enc.conv_in, B, W)
         self._wgrad(cvi, x_in, g_c0, enc.conv_in, acc)
+        self._join_side()
         self._db_batch.flush(self._colsum_ws, accumulate=acc)
         # ---- data-parallel: sum gradients over ranks (losses are normalised by the GLOBAL batch)
         if self.world_size > 1:
