@@ -1,0 +1,38 @@
+"""Measure the GEMM tile choices for the benchmark geometries on this GPU and write
+scrubvae_amd/tuned_tiles.json (careful timing: 12 repetitions per candidate)."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scrubvae_amd import ops
+from scrubvae_amd.data import synthetic
+from scrubvae_amd.get import model as get_model
+from scrubvae_amd.train.losses import get_batch_loss
+
+ops.TILE_TABLE = {}
+ops.AUTOTUNE_REPS = 12
+table = {}
+for joints, batch, full in ((23, 1024, False), (23, 1024, True), (23, 4096, False), (18, 1024, False), (23, 256, False)):
+    data, tree = synthetic.make_batch(joints, 64, batch, seed=0, device="cuda")
+    method = {"conditional": ["avg_speed_3d", "heading"], "grad_reversal": ["avg_speed_3d", "heading"], "adversarial_net": ["heading"]} if full else {}
+    feats = ["avg_speed_3d", "heading"] if full else []
+    loss = {"jpe": 1.0, "root": 1.0, "prior": 1.0}
+    if full:
+        loss.update({"avg_speed_3d_gr": 1.0, "heading_gr": 1.0, "heading_an": 1.0})
+    mc = dict(type="rcnn", kernel=5, z_dim=32, window=64, activation="prelu", diag=True, init_dilation=None, prior="gaussian",
+              channel=[64, 128, 256, 512, 1024])
+    dis = dict(method=method, alpha=1.0, features=feats)
+    m = get_model(mc, None, None, dis, joints, "midfwd", arena_size=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), kinematic_tree=tree,
+                  discrete_classes={"ids": torch.arange(4)} if full else None, device="cuda", verbose=0)
+    m.train()
+    m.overlap_wgrad = False
+    for _ in range(2):
+        bl = get_batch_loss(m, data, m(data), loss, dis)
+        bl["total"].backward()
+    torch.cuda.synchronize()
+    table.update(ops.TUNED_LOG)
+    print(f"J={joints} B={batch} full={full}: {len(ops.TUNED_LOG)} geometries tuned so far", flush=True)
+    del m
+    torch.cuda.empty_cache()
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tuned_tiles.json")
+json.dump(table, open(out, "w"), indent=0, sort_keys=True)
+print("wrote", out, len(table))
