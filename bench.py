@@ -31,6 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+PRODUCTS = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "bf16": 1}  # matrix-core products per algorithmic multiply
 
 
 def parse():
@@ -44,6 +46,9 @@ def parse():
     ap.add_argument("--full", action="store_true", help="configs[2]: conditional + grad-reversal + adversarial heads")
     ap.add_argument("--local-bn", action="store_true", help="per-rank BatchNorm statistics (no sync-BN collectives)")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph (single GPU)")
+    ap.add_argument("--precision", default=os.environ.get("SVAE_PRECISION", "f32"), choices=list(PRODUCTS),
+                    help="arithmetic of the large contractions: f32 = fp32 MFMA; bf16x6 = fp32-accurate 3-piece split on the bf16 "
+                         "matrix cores (6 products); bf16x3 / bf16 = 2 / 1 pieces (reduced accuracy, not a headline mode)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="timed region without the concurrent side streams (what the roofline region always uses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,6 +129,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    ops.set_precision(args.precision)
     from scrubvae_amd.data import synthetic
     method, feats, loss = make_cfg(args)
     B = args.batch
@@ -203,7 +209,9 @@ def main():
             "metric": "pose-windows/sec (ELBO-match) on synthetic 64-frame mouse skeletons",
             "value": round(B * world * args.steps / dt, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else f"f32 storage/accumulate, contractions as {args.precision} split on the bf16 matrix cores",
+            "data": "synthetic",
             "config": {"workload": ("configs[2] full SC-VAE (conditional + grad_reversal x2 + adversarial_net)" if args.full else
                                     "configs[1] mouse-skeleton rcnn, recon+KL (jpe+root+prior), AdamW") +
                                    f", batch {B}/GPU, window {args.window}, {args.joints} joints, z=32, channels [64,128,256,512,1024]",
@@ -219,12 +227,17 @@ def main():
                 # dominant kernel = the GEMM template instance with the largest total time
                 kname, s = max(summ.items(), key=lambda kv: kv[1]["ms"])
                 tf = s["flops"] / (s["ms"] * 1e-3) / 1e12
+                split_kernel = "bf16s" in kname
+                peak = PEAK_BF16_MFMA_TFLOPS / PRODUCTS[args.precision] if split_kernel else PEAK_F32_MFMA_TFLOPS
                 out["roofline"] = {"measured": f"second timed region of {args.steps} steps with the side HIP streams serialised "
                                                f"({dt_serial / args.steps * 1e3:.3f} ms/step; the headline region overlaps kernels "
                                                "on 3 streams, where a launch's duration is not the kernel's own time); "
                                                "profiles/*serial* is the rocprofv3 summary of `bench.py --serial-streams`",
-                                   "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic("svae::" + kname),
+                                   "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                                   "frac": round(tf / peak, 4), "traffic": pmc_traffic("svae::" + kname),
+                                   "peak_note": (f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {PRODUCTS[args.precision]} "
+                                                 "matrix-core products per algorithmic multiply (achieved counts algorithmic FLOPs)"
+                                                 if split_kernel else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                                    "kernel": "svae::" + kname,
                                    "launches_per_step": s["launches"] // args.steps,
                                    "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2),

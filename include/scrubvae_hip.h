@@ -80,6 +80,24 @@ size_t svae_conv_wgrad_workspace(const svae_conv_desc* d);
 int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const float* dy, float* dw,
                     float* db, void* ws, size_t ws_bytes, int accumulate, void* stream);
 
+/* ---- split-bf16 variants of the three contractions (scrubvae_amd/csrc/gemm_bf16s.hip) -----
+ * Same geometry, layouts and results contract as svae_conv_fwd / _dgrad / _wgrad, but the
+ * products run on the bf16 matrix cores: each fp32 operand is split into `pieces` (1..3) bf16
+ * pieces and the cross products with i + j < pieces are accumulated in fp32.  pieces = 3 is
+ * fp32-accurate (dropped terms O(2^-24)); 2 -> O(2^-16); 1 = plain bf16 operands.
+ * `wsplit` (svae_conv_split_bytes(d) bytes, caller-owned) holds the weight pieces written by
+ * svae_conv_split_weights from the fp32 master weights w[tap][c_in][c_out]; refresh it whenever
+ * the weights change.  d->tile[0..1]: V*1000000 + BM*1000 + BN, V = kernel variant (waves per
+ * workgroup / LDS buffering, see gemm_bf16s.hip). */
+size_t svae_conv_split_bytes(const svae_conv_desc* d);
+int svae_conv_split_weights(const svae_conv_desc* d, const float* w, void* wsplit, void* stream);
+int svae_conv_fwd_split(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias,
+                        float* y, int accumulate, int pieces, void* stream);
+int svae_conv_dgrad_split(const svae_conv_desc* d, const float* dy, const void* wsplit, float* dx,
+                          int accumulate, int pieces, void* stream);
+int svae_conv_wgrad_split(const svae_conv_desc* d, const float* x, const float* dy, float* dw,
+                          float* db, void* ws, size_t ws_bytes, int accumulate, int pieces, void* stream);
+
 /* introspection: the (BM, BN) workgroup tile the dispatcher uses; kind 0 fwd, 1 dgrad, 2 wgrad */
 int svae_conv_tile(const svae_conv_desc* d, int kind, int* bm, int* bn);
 

@@ -60,6 +60,11 @@ SIGNATURES = {
     "svae_conv_wgrad_workspace": (SZ, [DP]),
     "svae_conv_wgrad": (I, [DP, P, P, P, P, P, SZ, I, P]),
     "svae_conv_tile": (I, [DP, I, C.POINTER(I), C.POINTER(I)]),
+    "svae_conv_split_bytes": (SZ, [DP]),
+    "svae_conv_split_weights": (I, [DP, P, P, P]),
+    "svae_conv_fwd_split": (I, [DP, P, P, P, P, I, I, P]),
+    "svae_conv_dgrad_split": (I, [DP, P, P, P, I, I, P]),
+    "svae_conv_wgrad_split": (I, [DP, P, P, P, P, P, SZ, I, I, P]),
     "svae_pack_input": (I, [P, P, C.POINTER(F), P, LL, I, I, P]),
     "svae_bn_chunks": (I, [LL]),
     "svae_bn_stats_partial": (I, [P, LL, I, I, P, P]),

@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["capi.hip", "gemm_f32.hip", "elementwise.hip", "pose_tail.hip", "latent.hip"]
+SOURCES = ["capi.hip", "gemm_f32.hip", "gemm_bf16s.hip", "elementwise.hip", "pose_tail.hip", "latent.hip"]
 OUT = os.path.join(CSRC, "libscrubvae_hip.so")
 
 
@@ -12,7 +12,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + ["svae_internal.h"]]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + ["svae_internal.h", "gemm_common.h"]]
     deps.append(os.path.join(CSRC, "..", "..", "include", "scrubvae_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -1,0 +1,911 @@
+// Split-bf16 implicit-GEMM convolution kernels for gfx950 (MI355X).
+//
+// Same contractions, gather plans and layouts as gemm_f32.hip (reference:
+// src/scrubvae/model/residual.py:79-109,137-170,198,219-222,264,286 and their autograd), but
+// the products run on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate):
+// every fp32 operand is split into P bf16 pieces  x = x0 + x1 + x2  (each piece the leading
+// 8 significant bits of what is left, so three pieces hold all 24 bits of an fp32 exactly), and
+// the cross products with i + j < P are accumulated in fp32:
+//
+//   P = 3 : 6 MFMAs per 16-deep k-step; dropped terms are O(2^-24) relative -- the result is as
+//           accurate as the fp32 MFMA path (tests/studies/precision_bf16_split.py) at 6/16 of its
+//           matrix-core time;
+//   P = 2 : 3 MFMAs (error O(2^-16));   P = 1 : plain bf16 operands (error O(2^-8)).
+//
+// Activations stay fp32 in HBM and are split on the way into LDS (11 VALU per pair of elements,
+// hidden in the MFMA issue gaps); weights are split once per optimizer step by
+// split_weights_kernel into K-contiguous piece planes for both uses:
+//   Wf[piece][tap][c_out][c_in]  (forward: k = c_in)      Wd[piece][tap][c_in][c_out]  (dgrad: k = c_out)
+// so the weight operand needs no conversion and no transposed LDS read in the GEMM.
+// LDS image of a tile: [piece][row][SBK] bf16, 16-byte chunks XOR-swizzled by the row so that
+// the ds_read_b128 operand fetches are conflict-free without padding.
+#include "gemm_common.h"
+#include <type_traits>
+
+namespace svae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(unsigned, f); }
+__device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
+// {hi16(b), hi16(a)}: the truncated-bf16 pair (a in the low half = lower k)
+__device__ __forceinline__ unsigned pack_hi(float a, float b) { return __builtin_amdgcn_perm(f2u(b), f2u(a), 0x07060302u); }
+__device__ __forceinline__ unsigned pack_rne(float a, float b) {
+  bf16x2 t;
+  t[0] = (__bf16)a;
+  t[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ float residual(float x) { return x - u2f(f2u(x) & 0xffff0000u); }  // exact
+
+// split 4 consecutive-k floats into P pieces of 4 bf16 (8 bytes each)
+template <int P>
+__device__ __forceinline__ void split4(float4 v, uint2 (&out)[P]) {
+  float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if (p == P - 1) {
+      out[p].x = pack_rne(x[0], x[1]);
+      out[p].y = pack_rne(x[2], x[3]);
+    } else {
+      out[p].x = pack_hi(x[0], x[1]);
+      out[p].y = pack_hi(x[2], x[3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = residual(x[i]);
+    }
+  }
+}
+
+// 16-byte chunk c of LDS row `row` (64-byte rows = 32 bf16) sits at chunk position c ^ swz(row):
+// the ds_read_b128 operand fetch of 32 consecutive rows is then conflict-free without padding
+__device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
+
+__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// acc += sum over kept cross products of the pieces (small terms first)
+template <int P>
+__device__ __forceinline__ f32x16 mfma_split(const uint4 (&a)[P], const uint4 (&b)[P], f32x16 acc) {
+#pragma unroll
+  for (int s = P - 1; s >= 0; --s)
+#pragma unroll
+    for (int i = s; i >= 0; --i) acc = mfma_bf16(a[i], b[s - i], acc);
+  return acc;
+}
+
+constexpr int SBK = 32;  // K depth of one LDS stage: a 128-byte line of every gathered fp32 row
+
+struct SplitGatherArgs {
+  GatherArgs g;               // g.W / g.ldW / g.w_tap_stride unused
+  const unsigned short* Wp;   // weight pieces, pre-tiled [piece][tap][k/32][n][32] (zero padded in k)
+  long long w_piece_stride;   // elements between piece planes
+  int KB;                     // 32-deep k blocks per tap
+};
+
+// ------------------------------------------------------------------ gather GEMM (fwd / dgrad)
+// BM x BN tile per workgroup of WR x WC waves.  NSTAGE = 2: double-buffered LDS, one barrier per
+// K stage (register prefetch two stages ahead);  NSTAGE = 1: one LDS buffer, two barriers per
+// stage, half the LDS -> more workgroups per CU hide each other's conversion / barrier phases.
+template <int BM, int BN, int P, int WR, int WC, int NSTAGE, int MINW>
+__global__ __launch_bounds__(64 * WR * WC, MINW) void gather_gemm_bf16s_kernel(const SplitGatherArgs sa) {
+  const GatherArgs& g = sa.g;
+  constexpr int NTH = 64 * WR * WC;
+  constexpr int WM = BM / WR, MT = WM / 32, WN = BN / WC, NT = WN / 32;
+  static_assert(MT >= 1 && NT >= 1 && WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+  constexpr int RPP = NTH / 8;          // A rows per pass (8 lanes x float4 per row)
+  static_assert(BM % RPP == 0, "A rows must divide over the passes");
+  constexpr int APASS = BM / RPP;
+  constexpr int CH = 4;                 // 16-byte chunks per bf16 row
+  constexpr int B_CHUNKS = P * BN * CH;
+  constexpr int BPASS = (B_CHUNKS + NTH - 1) / NTH;
+  constexpr bool B_EXACT = B_CHUNKS % NTH == 0;
+  constexpr int ROWB = SBK * 2;         // bytes per LDS row
+  constexpr int A_PIECE = BM * ROWB, B_PIECE = BN * ROWB;
+  constexpr int STAGE = P * (A_PIECE + B_PIECE);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+  __shared__ long long rowoff[BM];
+
+  const int tid = threadIdx.x;
+  int bx = blockIdx.x, phase = 0;
+  if (bx >= g.blocks_m[0]) { phase = 1; bx -= g.blocks_m[0]; }
+  const long long m0 = (long long)bx * BM;
+  const int n0 = blockIdx.y * BN;
+  const long long Mp = g.M[phase];
+  const int nj = g.nj[phase];
+  const int ntaps = g.ntaps[phase];
+  const int* __restrict__ tap_base = g.base[phase];
+  const int* __restrict__ tap_w = g.widx[phase];
+
+  const int akq = tid & 7;
+  long long a_off[APASS];
+  int a_j[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const long long m = m0 + (tid >> 3) + RPP * i;
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      a_off[i] = b * (long long)g.Lin * g.ldA;
+      a_j[i] = j * g.sj;
+    } else {
+      a_off[i] = 0;
+      a_j[i] = -(1 << 28);
+    }
+  }
+  if (tid < BM) {
+    const long long m = m0 + tid;
+    long long off = -1;
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      off = (b * g.Lout + (phase + g.n_phase * j)) * (long long)g.ldC;
+    }
+    rowoff[tid] = off;
+  }
+  // B chunk owned by this thread in pass i: (piece, row, chunk); rows past N read row 0 and are zeroed
+  int b_lds[BPASS];
+  long long b_goff[BPASS];
+  bool b_in[BPASS];
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    const int idx = tid + NTH * i;
+    const int piece = (idx / (BN * CH)) % P, rem = idx % (BN * CH);
+    const int row = rem / CH, ch = rem % CH;
+    b_in[i] = (B_EXACT || idx < B_CHUNKS) && n0 + row < g.N;
+    b_goff[i] = (long long)piece * sa.w_piece_stride + (long long)(b_in[i] ? n0 + row : 0) * SBK + ch * 8;
+    b_lds[i] = P * A_PIECE + piece * B_PIECE + row * ROWB + ((ch ^ swz(row)) << 4);
+  }
+  const long long kb_stride = (long long)g.N * SBK;          // one (tap, k-block) slab of a piece plane
+  const long long tap_stride = kb_stride * sa.KB;
+
+  const int nk = ntaps * sa.KB;
+
+  float4 ra[APASS];
+  uint4 rb[BPASS];
+  bool ra_ok[APASS];
+  int nx_c0 = 0, nx_ti = 0;
+  int nx_tb = ntaps > 0 ? tap_base[0] : 0;
+  long long nx_woff = ntaps > 0 ? (long long)tap_w[0] * tap_stride : 0;
+  auto load_tile = [&]() {
+    const int c0 = nx_c0;
+    const int tb = nx_tb;
+    const unsigned short* wt = sa.Wp + nx_woff + (long long)(c0 >> 5) * kb_stride;
+    {
+      nx_c0 += SBK;
+      const bool wrap = nx_c0 >= g.Kc;
+      nx_c0 = wrap ? 0 : nx_c0;
+      nx_ti += wrap ? 1 : 0;
+      const int tic = nx_ti < ntaps ? nx_ti : ntaps - 1;
+      nx_tb = tap_base[tic];
+      nx_woff = (long long)tap_w[tic] * tap_stride;
+    }
+    const bool kq_ok = c0 + akq * 4 < g.Kc;
+    const int cq = kq_ok ? c0 + akq * 4 : 0;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int li = a_j[i] + tb;
+      const bool ok = li >= 0 && li < g.Lin;
+      const int lic = ok ? li : 0;
+      ra[i] = *reinterpret_cast<const float4*>(g.A + a_off[i] + (long long)lic * g.ldA + cq);
+      ra_ok[i] = ok && kq_ok;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) rb[i] = *reinterpret_cast<const uint4*>(wt + b_goff[i]);
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int row = (tid >> 3) + RPP * i;
+      uint2 pc[P];
+      split4<P>(ra_ok[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f), pc);
+      const int off = row * ROWB + (((akq >> 1) ^ swz(row)) << 4) + ((akq & 1) << 3);
+#pragma unroll
+      for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(st + p * A_PIECE + off) = pc[p];
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const uint4 v = b_in[i] ? rb[i] : make_uint4(0u, 0u, 0u, 0u);
+      if constexpr (B_EXACT) {
+        *reinterpret_cast<uint4*>(st + b_lds[i]) = v;
+      } else {
+        if (tid + NTH * i < B_CHUNKS) *reinterpret_cast<uint4*>(st + b_lds[i]) = v;
+      }
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave / WC, wc = wave % WC;
+  const int lr = lane & 31, h = lane >> 5;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](const unsigned char* st, int ks) {
+    uint4 av[MT][P], bv[NT][P];
+    const int ch = ks * 2 + h;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = wr * WM + mt * 32 + lr;
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        av[mt][p] = *reinterpret_cast<const uint4*>(st + p * A_PIECE + row * ROWB + ((ch ^ swz(row)) << 4));
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int row = wc * WN + nt * 32 + lr;
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        bv[nt][p] = *reinterpret_cast<const uint4*>(st + P * A_PIECE + p * B_PIECE + row * ROWB + ((ch ^ swz(row)) << 4));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_split<P>(av[mt], bv[nt], acc[mt][nt]);
+  };
+
+  if constexpr (NSTAGE == 2) {
+    if (nk > 0) {
+      load_tile();
+      store_tile(0);
+      if (nk > 1) load_tile();
+    }
+    __syncthreads();
+    auto k_tile = [&](int kt, auto do_store, auto do_load) {
+      const unsigned char* st = smem + (kt & 1) * STAGE;
+      if constexpr (decltype(do_store)::value) store_tile((kt & 1) ^ 1);
+      if constexpr (decltype(do_load)::value) load_tile();
+      compute(st, 0);
+      compute(st, 1);
+      __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) k_tile(kt, std::true_type{}, std::true_type{});
+    if (kt + 1 < nk) { k_tile(kt, std::true_type{}, std::false_type{}); ++kt; }
+    if (kt < nk) k_tile(kt, std::false_type{}, std::false_type{});
+  } else {
+    if (nk > 0) load_tile();
+    __syncthreads();  // rowoff
+    for (int kt = 0; kt < nk; ++kt) {
+      store_tile(0);
+      __syncthreads();
+      if (kt + 1 < nk) load_tile();
+      compute(smem, 0);
+      compute(smem, 1);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + wc * WN + nt * 32 + lr;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long off = rowoff[row];
+        if (off >= 0) {
+          float* dst = g.C + off + col;
+          float v = acc[mt][nt][r] + bv;
+          if (g.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------- gather GEMM, wave-specialised (fwd / dgrad)
+// In the kernel above all waves of a workgroup convert, then all run MFMAs: barrier-synchronised
+// waves sharing a SIMD are in the same phase, so the VALU/LDS-write time of the split adds to the
+// matrix-core time instead of hiding under it.  Here the roles are separated: waves 0-3 (one per
+// SIMD) are PRODUCERS -- they gather + split the next A tile and stage the next weight tile -- and
+// CWR x CWC CONSUMER waves only read operands from LDS and issue MFMAs.  Double-buffered LDS, one
+// barrier per K stage, executed once per stage by both roles.
+// DBG (timing experiments only, wrong results): 1 = producers issue no global loads, 2 = producers skip the
+// split (stage the raw bits), 4 = consumers issue no MFMAs, 8 = consumers issue no LDS reads
+template <int BM, int BN, int P, int CWR, int CWC, int D, int DBG = 0>
+__global__ __launch_bounds__(64 * (4 + CWR * CWC)) void gather_gemm_bf16s_ws_kernel(const SplitGatherArgs sa) {
+  const GatherArgs& g = sa.g;
+  constexpr int WM = BM / CWR, MT = WM / 32, WN = BN / CWC, NT = WN / 32;
+  static_assert(MT >= 1 && NT >= 1 && WM % 32 == 0 && WN % 32 == 0, "consumer tile must be a multiple of 32x32");
+  constexpr int NPT = 256;              // producer threads
+  constexpr int RPP = NPT / 8;
+  constexpr int APASS = BM / RPP;
+  constexpr int CH = 4;
+  constexpr int B_CHUNKS = P * BN * CH;
+  constexpr int BPASS = (B_CHUNKS + NPT - 1) / NPT;
+  constexpr bool B_EXACT = B_CHUNKS % NPT == 0;
+  constexpr int ROWB = SBK * 2;
+  constexpr int A_PIECE = BM * ROWB, B_PIECE = BN * ROWB;
+  constexpr int STAGE = P * (A_PIECE + B_PIECE);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  __shared__ long long rowoff[BM];
+
+  const int tid = threadIdx.x;
+  int bx = blockIdx.x, phase = 0;
+  if (bx >= g.blocks_m[0]) { phase = 1; bx -= g.blocks_m[0]; }
+  const long long m0 = (long long)bx * BM;
+  const int n0 = blockIdx.y * BN;
+  const long long Mp = g.M[phase];
+  const int nj = g.nj[phase];
+  const int ntaps = g.ntaps[phase];
+  const int nk = ntaps * sa.KB;
+
+  if (tid < NPT) {
+    // ================================================================== producer waves
+    const int* __restrict__ tap_base = g.base[phase];
+    const int* __restrict__ tap_w = g.widx[phase];
+    const int akq = tid & 7;
+    long long a_off[APASS];
+    int a_j[APASS];
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const long long m = m0 + (tid >> 3) + RPP * i;
+      if (m < Mp) {
+        const long long b = m / nj;
+        const int j = (int)(m - b * nj);
+        a_off[i] = b * (long long)g.Lin * g.ldA;
+        a_j[i] = j * g.sj;
+      } else {
+        a_off[i] = 0;
+        a_j[i] = -(1 << 28);
+      }
+    }
+    if (tid < BM) {
+      const long long m = m0 + tid;
+      long long off = -1;
+      if (m < Mp) {
+        const long long b = m / nj;
+        const int j = (int)(m - b * nj);
+        off = (b * g.Lout + (phase + g.n_phase * j)) * (long long)g.ldC;
+      }
+      rowoff[tid] = off;
+    }
+    int b_lds[BPASS];
+    long long b_goff[BPASS];
+    bool b_in[BPASS];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int idx = tid + NPT * i;
+      const int piece = (idx / (BN * CH)) % P, rem = idx % (BN * CH);
+      const int row = rem / CH, ch = rem % CH;
+      b_in[i] = (B_EXACT || idx < B_CHUNKS) && n0 + row < g.N;
+      b_goff[i] = (long long)piece * sa.w_piece_stride + (long long)(b_in[i] ? n0 + row : 0) * SBK + ch * 8;
+      b_lds[i] = P * A_PIECE + piece * B_PIECE + row * ROWB + ((ch ^ swz(row)) << 4);
+    }
+    const long long kb_stride = (long long)g.N * SBK;
+    const long long tap_stride = kb_stride * sa.KB;
+
+    // D register sets: the tile staged in stage kt was requested D stages earlier, so a producer
+    // wave (which has no MFMA phase to wait behind) never sits on a cold load
+    f32x4 ra[D][APASS];
+    u32x4 rb[D][BPASS];
+    bool ra_ok[D][APASS];
+    int nx_c0 = 0, nx_ti = 0;
+    int nx_tb = ntaps > 0 ? tap_base[0] : 0;
+    long long nx_woff = ntaps > 0 ? (long long)tap_w[0] * tap_stride : 0;
+    auto load_tile = [&](auto slot_c) {
+      constexpr int S = decltype(slot_c)::value;
+      const int c0 = nx_c0;
+      const int tb = nx_tb;
+      const unsigned short* wt = sa.Wp + nx_woff + (long long)(c0 >> 5) * kb_stride;
+      {
+        nx_c0 += SBK;
+        const bool wrap = nx_c0 >= g.Kc;
+        nx_c0 = wrap ? 0 : nx_c0;
+        nx_ti += wrap ? 1 : 0;
+        const int tic = nx_ti < ntaps ? nx_ti : ntaps - 1;
+        nx_tb = tap_base[tic];
+        nx_woff = (long long)tap_w[tic] * tap_stride;
+      }
+      const bool kq_ok = c0 + akq * 4 < g.Kc;
+      const int cq = kq_ok ? c0 + akq * 4 : 0;
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        const int li = a_j[i] + tb;
+        const bool ok = li >= 0 && li < g.Lin;
+        const int lic = ok ? li : 0;
+        if constexpr (!(DBG & 1)) ra[S][i] = *reinterpret_cast<const f32x4*>(g.A + a_off[i] + (long long)lic * g.ldA + cq);
+        ra_ok[S][i] = ok && kq_ok;
+      }
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i)
+        if constexpr (!(DBG & 1)) rb[S][i] = *reinterpret_cast<const u32x4*>(wt + b_goff[i]);
+    };
+    auto store_tile = [&](int buf, auto slot_c) {
+      constexpr int S = decltype(slot_c)::value;
+      unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        const u32x4 v = b_in[i] ? rb[S][i] : u32x4{0u, 0u, 0u, 0u};
+        if constexpr (B_EXACT) {
+          *reinterpret_cast<u32x4*>(st + b_lds[i]) = v;
+        } else {
+          if (tid + NPT * i < B_CHUNKS) *reinterpret_cast<u32x4*>(st + b_lds[i]) = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        const int row = (tid >> 3) + RPP * i;
+        uint2 pc[P];
+        const f32x4 a = ra[S][i];
+        if constexpr (DBG & 2) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) pc[p] = make_uint2(f2u(a.x) + p, f2u(a.y));
+        } else {
+          split4<P>(ra_ok[S][i] ? make_float4(a.x, a.y, a.z, a.w) : make_float4(0.f, 0.f, 0.f, 0.f), pc);
+        }
+        const int off = row * ROWB + (((akq >> 1) ^ swz(row)) << 4) + ((akq & 1) << 3);
+#pragma unroll
+        for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(st + p * A_PIECE + off) = pc[p];
+      }
+    };
+    // tile t lives in register set t % D.  Loads past the last tile are harmless re-reads of the
+    // last tap (clamped addresses) that are never staged.
+    if (nk > 0) {
+      load_tile(std::integral_constant<int, 0>{});
+      if constexpr (D > 1) load_tile(std::integral_constant<int, 1 % D>{});
+      if constexpr (D > 2) load_tile(std::integral_constant<int, 2 % D>{});
+      store_tile(0, std::integral_constant<int, 0>{});
+      load_tile(std::integral_constant<int, 0>{});  // tile D
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    // stage kt stages tile kt+1 (set (kt+1) % D) and requests tile kt+1+D into the same set
+    // unconditional on purpose: a conditional load makes hipcc fall back to vmcnt(0) waits, which
+    // collapses the prefetch distance.  Past the end the loads re-read the last tap (clamped, in
+    // bounds) and the store fills the LDS buffer nobody reads any more.
+    auto stage = [&](int kt, auto slot_c) {
+      store_tile((kt & 1) ^ 1, slot_c);
+      load_tile(slot_c);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise hoists the NEXT stage's conversion above this barrier -> vmcnt(0)
+    };
+    int kt = 0;
+    for (; kt + D <= nk; kt += D) {
+      stage(kt, std::integral_constant<int, 1 % D>{});
+      if constexpr (D > 1) stage(kt + 1, std::integral_constant<int, 2 % D>{});
+      if constexpr (D > 2) stage(kt + 2, std::integral_constant<int, 3 % D>{});
+    }
+    if (kt < nk) { stage(kt, std::integral_constant<int, 1 % D>{}); ++kt; }
+    if constexpr (D > 2) { if (kt < nk) { stage(kt, std::integral_constant<int, 2 % D>{}); ++kt; } }
+    return;
+  }
+
+  // ==================================================================== consumer waves
+  const int ctid = tid - NPT;
+  const int wave = ctid >> 6, lane = ctid & 63;
+  const int wr = wave / CWC, wc = wave % CWC;
+  const int lr = lane & 31, h = lane >> 5;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int a_addr[MT], b_addr[NT], a_sw[MT], b_sw[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = wr * WM + mt * 32 + lr;
+    a_addr[mt] = row * ROWB;
+    a_sw[mt] = swz(row);
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int row = wc * WN + nt * 32 + lr;
+    b_addr[nt] = P * A_PIECE + row * ROWB;
+    b_sw[nt] = swz(row);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 av[MT][P], bv[NT][P];
+      const int ch = ks * 2 + h;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if constexpr (DBG & 8) av[mt][p] = make_uint4(kt, ks, mt, p);
+          else av[mt][p] = *reinterpret_cast<const uint4*>(st + p * A_PIECE + a_addr[mt] + ((ch ^ a_sw[mt]) << 4));
+        }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if constexpr (DBG & 8) bv[nt][p] = make_uint4(kt, ks, nt, p);
+          else bv[nt][p] = *reinterpret_cast<const uint4*>(st + p * B_PIECE + b_addr[nt] + ((ch ^ b_sw[nt]) << 4));
+        }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (DBG & 4) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[mt][nt][p] += __builtin_bit_cast(float, av[mt][p].x ^ bv[nt][p].y);
+          } else {
+            acc[mt][nt] = mfma_split<P>(av[mt], bv[nt], acc[mt][nt]);
+          }
+        }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + wc * WN + nt * 32 + lr;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long off = rowoff[row];
+        if (off >= 0) {
+          float* dst = g.C + off + col;
+          float v = acc[mt][nt][r] + bv;
+          if (g.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- weight split
+// w[tap][c_in][c_out] fp32 -> bf16 piece planes, pre-tiled in the order the GEMM stages them:
+//   plane(n, k) at [piece][tap][k/32][n][k%32], k zero-padded to a multiple of 32.
+//   Wf: n = c_out, k = c_in (forward)      Wd: n = c_in, k = c_out (data gradient)
+// One workgroup converts a 32 (n) x 32 (k) block; Wf goes through an LDS transpose.
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                            int T, int Cin, int Cout, int to_wd, long long piece_stride) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int N = to_wd ? Cin : Cout, K = to_wd ? Cout : Cin;
+  const int KB = (K + 31) / 32;
+  const int nb = blockIdx.x, kb = blockIdx.y, t = blockIdx.z;
+  const int n0 = nb * 32, k0 = kb * 32;
+  float v[4];
+  if (to_wd) {  // source rows are n (= c_in), contiguous in k (= c_out)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + ty + 8 * i, k = k0 + tx;
+      v[i] = (n < N && k < K) ? w[((long long)t * Cin + n) * Cout + k] : 0.f;
+    }
+  } else {      // source rows are k (= c_in), contiguous in n (= c_out): transpose
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + ty + 8 * i, n = n0 + tx;
+      tile[ty + 8 * i][tx] = (n < N && k < K) ? w[((long long)t * Cin + k) * Cout + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = tile[tx][ty + 8 * i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i;
+    if (n >= N) continue;
+    float x = v[i];
+    const long long o = (((long long)t * KB + kb) * N + n) * 32 + tx;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const unsigned u = p == 2 ? (pack_rne(x, 0.f) & 0xffffu) : (f2u(x) >> 16);
+      out[p * piece_stride + o] = (unsigned short)u;
+      x = residual(x);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ weight grad
+// dW_t[c][n] = sum_r X[xrow(r,t)][c] * dY[yrow(r,t)][n]: the contraction runs over ROWS, so both
+// operands are transposed on the way into LDS: a thread owns 4 reduction rows x 4 channels, splits
+// them and writes, per channel, the 4 row-values as 8 bytes of that channel's K-contiguous LDS row
+// (image [piece][channel][16 k + pad], 48-byte rows: conflict-free ds_read_b128 operand fetches).
+constexpr int WSK = 16;
+constexpr int WROWB = 48;
+
+template <int BM, int BN, int P>
+__global__ __launch_bounds__(256, 2) void wgrad_gemm_bf16s_kernel(const WgradArgs g) {
+  constexpr int WM = BM / 2, MT = WM / 32, WN = BN / 2, NT = WN / 32;
+  constexpr int A_PIECE = BM * WROWB, B_PIECE = BN * WROWB;
+  constexpr int STAGE = P * (A_PIECE + B_PIECE);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int ti = blockIdx.x / g.ctiles;
+  const int c0 = (blockIdx.x - ti * g.ctiles) * BM;
+  const int n0 = blockIdx.y * BN;
+  const long long r_begin = (long long)blockIdx.z * g.rows_per_split;
+  long long r_end = r_begin + g.rows_per_split;
+  if (r_end > g.R) r_end = g.R;
+  const int tbx = g.bx[ti], tby = g.by[ti];
+
+  // staging unit of this thread: operand (A = X channels, B = dY channels), row group rg, channel quad cq
+  const bool is_a = tid < BM;
+  const bool has_unit = tid < BM + BN;
+  const int u = is_a ? tid : tid - BM;
+  const int rg = u & 3, cq = u >> 2;
+  const int ch0 = (is_a ? c0 : n0) + cq * 4;
+  const bool col_ok = has_unit && ch0 < (is_a ? g.Kc : g.N);
+  const float* const base = is_a ? g.X : g.dY;
+  const int ld = is_a ? g.ldX : g.ldY;
+  const int L = is_a ? g.Lx : g.Ly;
+  const int s = is_a ? g.sx : g.sy;
+  const int tb = is_a ? tbx : tby;
+  const long long row_step = (long long)s * ld;                       // next reduction row, same sample
+  const long long row_wrap = ((long long)L - (long long)g.nj * s) * ld;  // extra when j wraps into the next sample
+  const int q16 = WSK / g.nj, r16 = WSK % g.nj;
+  const long long st_step = ((long long)q16 * L + (long long)r16 * s) * ld;
+  int jj;
+  const float* ptr;
+  long long left;
+  {
+    const long long r = r_begin + rg * 4;
+    const long long b = r / g.nj;
+    jj = (int)(r - b * g.nj);
+    ptr = base + (b * L + (long long)jj * s + tb) * (long long)ld + (col_ok ? ch0 : 0);
+    left = r_end - r;
+  }
+  const int lds_unit = (is_a ? 0 : P * A_PIECE) + (cq * 4) * WROWB + rg * 8;
+
+  float4 rv[4];
+  bool rv_ok[4];
+  auto load_tile = [&]() {
+    int j = jj;
+    const float* p = ptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int xr = j * g.sx + tbx, yr = j * g.sy + tby;
+      const bool ok = col_ok && left > i && xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly;
+      rv[i] = *reinterpret_cast<const float4*>(ok ? p : base);
+      rv_ok[i] = ok;
+      ++j;
+      p += row_step;
+      if (j >= g.nj) { j = 0; p += row_wrap; }
+    }
+    jj += r16;
+    ptr += st_step;
+    left -= WSK;
+    if (jj >= g.nj) { jj -= g.nj; ptr += row_wrap; }
+  };
+  auto store_tile = [&](int buf) {
+    if (!has_unit) return;
+    unsigned char* st = smem + buf * STAGE + lds_unit;
+    float v[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i][0] = rv_ok[i] ? rv[i].x : 0.f;
+      v[i][1] = rv_ok[i] ? rv[i].y : 0.f;
+      v[i][2] = rv_ok[i] ? rv[i].z : 0.f;
+      v[i][3] = rv_ok[i] ? rv[i].w : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint2 pc[P];
+      split4<P>(make_float4(v[0][c], v[1][c], v[2][c], v[3][c]), pc);
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        *reinterpret_cast<uint2*>(st + p * (is_a ? A_PIECE : B_PIECE) + c * WROWB) = pc[p];
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 31, h = lane >> 5;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (int)((r_end - r_begin + WSK - 1) / WSK);
+  if (nk > 0) {
+    load_tile();
+    store_tile(0);
+    if (nk > 1) load_tile();
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+    uint4 av[MT][P], bv[NT][P];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        av[mt][p] = *reinterpret_cast<const uint4*>(st + p * A_PIECE + (wr * WM + mt * 32 + lr) * WROWB + h * 16);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        bv[nt][p] = *reinterpret_cast<const uint4*>(st + P * A_PIECE + p * B_PIECE + (wc * WN + nt * 32 + lr) * WROWB + h * 16);
+    if (kt + 1 < nk) store_tile((kt & 1) ^ 1);
+    if (kt + 2 < nk) load_tile();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_split<P>(av[mt], bv[nt], acc[mt][nt]);
+    __syncthreads();
+  }
+
+  float* out = g.out + (long long)blockIdx.z * g.slab_stride + (long long)ti * g.Kc * g.ldW;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + wc * WN + nt * 32 + lr;
+    if (col >= g.N) continue;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (c < g.Kc) {
+          float* dst = out + (long long)c * g.ldW + col;
+          float v = acc[mt][nt][r];
+          if (g.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+static void launch_wgrad_p(const WgradArgs& g, dim3 grid, hipStream_t st, int pieces) {
+  if (pieces == 3) hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 3>), grid, dim3(256), 0, st, g);
+  else if (pieces == 2) hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 2>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 1>), grid, dim3(256), 0, st, g);
+}
+
+int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int pieces) {
+  if (bm == 128 && bn == 128) launch_wgrad_p<128, 128>(g, grid, st, pieces);
+  else if (bm == 128 && bn == 64) launch_wgrad_p<128, 64>(g, grid, st, pieces);
+  else if (bm == 64 && bn == 128) launch_wgrad_p<64, 128>(g, grid, st, pieces);
+  else launch_wgrad_p<64, 64>(g, grid, st, pieces);
+  return check_launch("wgrad_gemm_bf16s");
+}
+
+// ------------------------------------------------------------------------------ host side
+// layout of the split-weight buffer: [Wf: 3 planes][Wd: 3 planes], plane sizes in elements
+static inline long long plane_f(const svae_conv_desc* d) { return (long long)d->kernel * ((d->c_in + 31) / 32) * 32 * d->c_out; }
+static inline long long plane_d(const svae_conv_desc* d) { return (long long)d->kernel * ((d->c_out + 31) / 32) * 32 * d->c_in; }
+
+template <int BM, int BN, int WR, int WC, int NSTAGE, int MINW>
+static void launch_split_p(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces) {
+  const dim3 block(64 * WR * WC);
+  if (pieces == 3) hipLaunchKernelGGL((gather_gemm_bf16s_kernel<BM, BN, 3, WR, WC, NSTAGE, MINW>), grid, block, 0, st, sa);
+  else if (pieces == 2) hipLaunchKernelGGL((gather_gemm_bf16s_kernel<BM, BN, 2, WR, WC, NSTAGE, MINW>), grid, block, 0, st, sa);
+  else hipLaunchKernelGGL((gather_gemm_bf16s_kernel<BM, BN, 1, WR, WC, NSTAGE, MINW>), grid, block, 0, st, sa);
+}
+
+template <int BM, int BN, int CWR, int CWC, int D>
+static void launch_split_ws(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces) {
+  const dim3 block(64 * (4 + CWR * CWC));
+  if (pieces == 3) hipLaunchKernelGGL((gather_gemm_bf16s_ws_kernel<BM, BN, 3, CWR, CWC, D>), grid, block, 0, st, sa);
+  else if (pieces == 2) hipLaunchKernelGGL((gather_gemm_bf16s_ws_kernel<BM, BN, 2, CWR, CWC, D>), grid, block, 0, st, sa);
+  else hipLaunchKernelGGL((gather_gemm_bf16s_ws_kernel<BM, BN, 1, CWR, CWC, D>), grid, block, 0, st, sa);
+}
+
+static void launch_split_dbg(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int dbg) {
+  const dim3 block(64 * 12);
+#define SVAE_DBG_CASE(N) case N: hipLaunchKernelGGL((gather_gemm_bf16s_ws_kernel<128, 128, 3, 4, 2, 2, N>), grid, block, 0, st, sa); break;
+  switch (dbg) {
+    SVAE_DBG_CASE(0) SVAE_DBG_CASE(1) SVAE_DBG_CASE(2) SVAE_DBG_CASE(3) SVAE_DBG_CASE(4) SVAE_DBG_CASE(8) SVAE_DBG_CASE(12)
+    SVAE_DBG_CASE(5) SVAE_DBG_CASE(13) SVAE_DBG_CASE(15) SVAE_DBG_CASE(7)
+    default: break;
+  }
+#undef SVAE_DBG_CASE
+}
+
+// tile code V*1000000 + BM*1000 + BN.  V = 0: 4 waves, double-buffered LDS;  1: 4 waves, single LDS buffer;
+// 2: 8 waves (4x2), single buffer;  3: 8 waves, double-buffered (BM = 128 only);
+// 4: wave-specialised, 4 producer + 8 consumer waves, 2 tiles in flight;  5: same with 4 consumers;
+// 6 / 7: as 4 / 5 with 3 tiles in flight
+static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, int pieces) {
+  GatherArgs& g = sa.g;
+  Tile t;
+  if (!decode_tile(code, t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
+  for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + t.bm - 1) / t.bm);
+  const int bm = g.blocks_m[0] + g.blocks_m[1];
+  if (bm == 0) return SVAE_OK;
+  dim3 grid(bm, (g.N + t.bn - 1) / t.bn);
+  const int v = t.dma;
+#define SVAE_SPLIT_CASE(BM_, BN_)                                                          \
+  if (t.bm == BM_ && t.bn == BN_) {                                                        \
+    if (v == 0) launch_split_p<BM_, BN_, 2, 2, 2, 1>(sa, grid, st, pieces);                \
+    else if (v == 1) launch_split_p<BM_, BN_, 2, 2, 1, 2>(sa, grid, st, pieces);           \
+    else if (v == 2 && BM_ == 128) launch_split_p<128, BN_, 4, 2, 1, 2>(sa, grid, st, pieces); \
+    else if (v == 3 && BM_ == 128) launch_split_p<128, BN_, 4, 2, 2, 1>(sa, grid, st, pieces); \
+    else if (v == 4 && BM_ == 128) launch_split_ws<128, BN_, 4, 2, 2>(sa, grid, st, pieces);  \
+    else if (v == 4 && BN_ == 128) launch_split_ws<64, 128, 2, 4, 2>(sa, grid, st, pieces);   \
+    else if (v == 5) launch_split_ws<BM_, BN_, 2, 2, 2>(sa, grid, st, pieces);                \
+    else if (v == 6 && BM_ == 128) launch_split_ws<128, BN_, 4, 2, 3>(sa, grid, st, pieces);  \
+    else if (v == 6 && BN_ == 128) launch_split_ws<64, 128, 2, 4, 3>(sa, grid, st, pieces);   \
+    else if (v == 7) launch_split_ws<BM_, BN_, 2, 2, 3>(sa, grid, st, pieces);                \
+    else if (v >= 10 && v < 26 && BM_ == 128 && BN_ == 128 && pieces == 3) launch_split_dbg(sa, grid, st, v - 10); \
+    else { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_ARG; } \
+  }
+  SVAE_SPLIT_CASE(128, 128) else SVAE_SPLIT_CASE(128, 64) else SVAE_SPLIT_CASE(64, 128) else SVAE_SPLIT_CASE(64, 64)
+#undef SVAE_SPLIT_CASE
+  return check_launch("gather_gemm_bf16s");
+}
+
+}  // namespace svae
+
+using namespace svae;
+
+extern "C" size_t svae_conv_split_bytes(const svae_conv_desc* d) {
+  if (validate(d)) return 0;
+  return (size_t)3 * (plane_f(d) + plane_d(d)) * sizeof(unsigned short);
+}
+
+extern "C" int svae_conv_split_weights(const svae_conv_desc* d, const float* w, void* wsplit, void* stream) {
+  if (int e = validate(d)) return e;
+  SVAE_REQUIRE(w && wsplit && aligned16(w) && aligned16(wsplit), SVAE_ERR_ARG, "conv_split_weights: null / unaligned pointer");
+  unsigned short* out = (unsigned short*)wsplit;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(split_weights_kernel, dim3((d->c_out + 31) / 32, (d->c_in + 31) / 32, d->kernel), dim3(256), 0, st, w, out,
+                     d->kernel, d->c_in, d->c_out, 0, plane_f(d));
+  hipLaunchKernelGGL(split_weights_kernel, dim3((d->c_in + 31) / 32, (d->c_out + 31) / 32, d->kernel), dim3(256), 0, st, w,
+                     out + 3 * plane_f(d), d->kernel, d->c_in, d->c_out, 1, plane_d(d));
+  return check_launch("split_weights");
+}
+
+extern "C" int svae_conv_fwd_split(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias, float* y,
+                                   int accumulate, int pieces, void* stream) {
+  if (int e = validate(d)) return e;
+  SVAE_REQUIRE(x && wsplit && y, SVAE_ERR_ARG, "conv_fwd_split: null pointer");
+  SVAE_REQUIRE(aligned16(x) && aligned16(wsplit) && aligned16(y), SVAE_ERR_ALIGN, "conv_fwd_split: pointers must be 16-byte aligned");
+  SVAE_REQUIRE(pieces >= 1 && pieces <= 3, SVAE_ERR_ARG, "conv_fwd_split: pieces %d not in 1..3", pieces);
+  SplitGatherArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  GatherArgs& g = sa.g;
+  sa.Wp = (const unsigned short*)wsplit;  // Wf planes
+  sa.w_piece_stride = plane_f(d);
+  sa.KB = (d->c_in + 31) / 32;
+  g.A = x; g.bias = bias; g.C = y;
+  g.Kc = d->c_in; g.ldA = d->ld_in; g.ldC = d->ld_out;
+  g.N = d->c_out;
+  g.accumulate = accumulate;
+  build_plan(g, d, /*strided=*/!d->transposed, d->l_out, d->l_in);
+  return launch_split_gather(sa, (hipStream_t)stream, d->tile[0], pieces);
+}
+
+extern "C" int svae_conv_dgrad_split(const svae_conv_desc* d, const float* dy, const void* wsplit, float* dx, int accumulate,
+                                     int pieces, void* stream) {
+  if (int e = validate(d)) return e;
+  SVAE_REQUIRE(dy && wsplit && dx, SVAE_ERR_ARG, "conv_dgrad_split: null pointer");
+  SVAE_REQUIRE(aligned16(dy) && aligned16(wsplit) && aligned16(dx), SVAE_ERR_ALIGN, "conv_dgrad_split: pointers must be 16-byte aligned");
+  SVAE_REQUIRE(pieces >= 1 && pieces <= 3, SVAE_ERR_ARG, "conv_dgrad_split: pieces %d not in 1..3", pieces);
+  SplitGatherArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  GatherArgs& g = sa.g;
+  sa.Wp = (const unsigned short*)wsplit + 3 * plane_f(d);  // Wd planes
+  sa.w_piece_stride = plane_d(d);
+  sa.KB = (d->c_out + 31) / 32;
+  g.A = dy; g.bias = nullptr; g.C = dx;
+  g.Kc = d->c_out; g.ldA = d->ld_out; g.ldC = d->ld_in;
+  g.N = d->c_in;
+  g.accumulate = accumulate;
+  build_plan(g, d, /*strided=*/d->transposed != 0, d->l_in, d->l_out);
+  return launch_split_gather(sa, (hipStream_t)stream, d->tile[1], pieces);
+}

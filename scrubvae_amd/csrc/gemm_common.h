@@ -1,0 +1,135 @@
+// Shared by the fp32 (gemm_f32.hip) and split-bf16 (gemm_bf16s.hip) implicit-GEMM kernels:
+// the gather plan of a convolution and the workgroup-tile selection.
+#pragma once
+#include "svae_internal.h"
+
+namespace svae {
+
+struct GatherArgs {
+  const float* A;
+  const float* W;
+  const float* bias;
+  float* C;
+  long long M[2];  // rows per phase = batch * nj[p]
+  int nj[2];
+  int ntaps[2];
+  int base[2][SVAE_MAX_TAPS];  // li = j*sj + base
+  int widx[2][SVAE_MAX_TAPS];  // weight tap of that entry
+  int blocks_m[2];
+  int Lin, Lout, sj, n_phase;
+  int Kc;  // reduction channels per tap, multiple of 16
+  int ldA, ldC, ldW;
+  long long w_tap_stride;
+  int N;  // padded output channels
+  int accumulate;
+};
+
+inline int validate(const svae_conv_desc* d) {
+  SVAE_REQUIRE(d != nullptr, SVAE_ERR_ARG, "conv: null descriptor");
+  SVAE_REQUIRE(d->batch > 0 && d->l_in > 0 && d->l_out > 0, SVAE_ERR_SHAPE, "conv: non-positive batch/length");
+  SVAE_REQUIRE(d->c_in > 0 && d->c_out > 0 && d->c_in % 16 == 0 && d->c_out % 16 == 0, SVAE_ERR_SHAPE,
+               "conv: padded channel counts must be positive multiples of 16 (got %d,%d)", d->c_in, d->c_out);
+  SVAE_REQUIRE(d->ld_in >= d->c_in && d->ld_out >= d->c_out && d->ld_in % 4 == 0 && d->ld_out % 4 == 0, SVAE_ERR_ALIGN,
+               "conv: leading dimensions must be >= channels and multiples of 4");
+  SVAE_REQUIRE(d->kernel >= 1 && d->kernel <= SVAE_MAX_TAPS, SVAE_ERR_SHAPE, "conv: kernel %d not in [1,%d]", d->kernel,
+               SVAE_MAX_TAPS);
+  SVAE_REQUIRE(d->stride == 1 || d->stride == 2, SVAE_ERR_SHAPE, "conv: stride %d unsupported", d->stride);
+  SVAE_REQUIRE(d->dilation >= 1 && d->padding >= 0, SVAE_ERR_SHAPE, "conv: bad dilation/padding");
+  int expect;
+  if (!d->transposed)
+    expect = (d->l_in + 2 * d->padding - d->dilation * (d->kernel - 1) - 1) / d->stride + 1;
+  else
+    expect = (d->l_in - 1) * d->stride - 2 * d->padding + d->dilation * (d->kernel - 1) + 1;
+  SVAE_REQUIRE(expect == d->l_out, SVAE_ERR_SHAPE, "conv: l_out %d != formula %d", d->l_out, expect);
+  return SVAE_OK;
+}
+
+// Build the gather plan.  strided=true: src = j*stride + t*dil - pad (one phase);
+// strided=false: src = (dst + pad - t*dil)/stride, split by dst parity.
+inline void build_plan(GatherArgs& g, const svae_conv_desc* d, bool strided, int Ldst, int Lsrc) {
+  g.Lin = Lsrc;
+  g.Lout = Ldst;
+  for (int p = 0; p < 2; ++p) { g.nj[p] = 0; g.ntaps[p] = 0; g.M[p] = 0; g.blocks_m[p] = 0; }
+  if (strided) {
+    g.n_phase = 1;
+    g.sj = d->stride;
+    g.nj[0] = Ldst;
+    g.ntaps[0] = d->kernel;
+    for (int t = 0; t < d->kernel; ++t) { g.base[0][t] = t * d->dilation - d->padding; g.widx[0][t] = t; }
+  } else {
+    const int s = d->stride;
+    g.n_phase = s;
+    g.sj = 1;
+    for (int p = 0; p < s; ++p) {
+      g.nj[p] = (Ldst - p + s - 1) / s;
+      if (g.nj[p] < 0) g.nj[p] = 0;
+      int n = 0;
+      for (int t = 0; t < d->kernel; ++t) {
+        const int num = p + d->padding - t * d->dilation;
+        if (((num % s) + s) % s != 0) continue;
+        g.base[p][n] = num / s;  // exact division
+        g.widx[p][n] = t;
+        ++n;
+      }
+      g.ntaps[p] = n;
+    }
+  }
+  for (int p = 0; p < g.n_phase; ++p) g.M[p] = (long long)d->batch * g.nj[p];
+}
+
+// ---- tile selection.  Per-block work is MFMA-bound and co-resident blocks hide each other's
+// barrier / LDS-fill stalls, so prefer the largest tile that still gives >= 2 blocks per CU;
+// below that, more (smaller) blocks win.  Scores are relative throughput estimates.
+struct Tile { int bm, bn; int dma = 0; };
+
+inline double tile_score(long long M0, long long M1, int N, int bm, int bn) {
+  const long long bmk = (M0 + bm - 1) / bm + (M1 + bm - 1) / bm;
+  const long long bnk = (N + bn - 1) / bn;
+  const long long blocks = bmk * bnk;
+  if (blocks == 0) return 0.0;
+  const double useful = (double)(M0 + M1) * N / ((double)bmk * bm * bnk * bn);
+  const double resident = 256.0 * (bm * bn >= 128 * 128 ? 2.0 : 3.0);  // blocks the chip holds at once
+  const double waves = (double)((blocks + (long long)resident - 1) / (long long)resident);
+  const double fill = (double)blocks / (waves * resident);
+  const double occ = blocks >= 512 ? 1.0 : (blocks >= 256 ? 0.8 : 0.8 * blocks / 256.0);
+  const double teff = (bm * bn >= 128 * 128) ? 1.0 : (bm * bn >= 64 * 128 ? 0.93 : 0.85);
+  return useful * teff * occ * (0.5 + 0.5 * fill);
+}
+
+inline Tile pick_tile(long long M0, long long M1, int N) {
+  const Tile cand[4] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  Tile best = cand[0];
+  double bs = -1.0;
+  for (const Tile& t : cand) {
+    const double sc = tile_score(M0, M1, N, t.bm, t.bn);
+    if (sc > bs * 1.001) { bs = sc; best = t; }
+  }
+  return best;
+}
+
+inline bool decode_tile(int code, Tile& t) {
+  if (code <= 0) return false;
+  t.dma = code / 1000000;  // VBBBNNN: kernel variant (fp32 gather: 1 = LDS-DMA staging; split-bf16: see gemm_bf16s.hip)
+  code %= 1000000;
+  t.bm = code / 1000;
+  t.bn = code % 1000;
+  return (t.bm == 64 || t.bm == 128) && (t.bn == 64 || t.bn == 128);
+}
+
+struct WgradArgs {
+  const float* X;
+  const float* dY;
+  float* out;  // slab base [nsplit][T][Kc][ldW] or dw itself when nsplit == 1
+  long long R;  // reduction rows = batch * nj
+  long long rows_per_split;
+  long long slab_stride;
+  int nj, Lx, Ly, sx, sy;
+  int bx[SVAE_MAX_TAPS], by[SVAE_MAX_TAPS];
+  int T, Kc, N, ldX, ldY, ldW, ctiles, bm;
+  int accumulate;
+};
+
+// split-bf16 weight-gradient main kernel (gemm_bf16s.hip); same grid / slabs as wgrad_gemm_kernel
+int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int pieces);
+
+}  // namespace svae

@@ -22,7 +22,7 @@
 // Row-contiguous operands sit as [k][cols] and are fetched with conflict-free ds_read_b32.
 // Two LDS stages + register prefetch (global loads of tile k+1 are issued before the MFMAs
 // of tile k, written to LDS after them): one barrier per K tile.
-#include "svae_internal.h"
+#include "gemm_common.h"
 #include <type_traits>
 
 namespace svae {
@@ -32,24 +32,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;
 constexpr int LDK = BK + 4;  // padded row of a K-contiguous LDS tile (conflict-free b128)
 
-struct GatherArgs {
-  const float* A;
-  const float* W;
-  const float* bias;
-  float* C;
-  long long M[2];  // rows per phase = batch * nj[p]
-  int nj[2];
-  int ntaps[2];
-  int base[2][SVAE_MAX_TAPS];  // li = j*sj + base
-  int widx[2][SVAE_MAX_TAPS];  // weight tap of that entry
-  int blocks_m[2];
-  int Lin, Lout, sj, n_phase;
-  int Kc;  // reduction channels per tap, multiple of 16
-  int ldA, ldC, ldW;
-  long long w_tap_stride;
-  int N;  // padded output channels
-  int accumulate;
-};
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -491,18 +473,6 @@ __global__ __launch_bounds__(256) void gather_gemm_dma_kernel(const GatherArgs g
 }
 
 // ------------------------------------------------------------------------- weight grad
-struct WgradArgs {
-  const float* X;
-  const float* dY;
-  float* out;  // slab base [nsplit][T][Kc][ldW] or dw itself when nsplit == 1
-  long long R;  // reduction rows = batch * nj
-  long long rows_per_split;
-  long long slab_stride;
-  int nj, Lx, Ly, sx, sy;
-  int bx[SVAE_MAX_TAPS], by[SVAE_MAX_TAPS];
-  int T, Kc, N, ldX, ldY, ldW, ctiles, bm;
-  int accumulate;
-};
 
 constexpr int WBK = 16;  // reduction rows per LDS stage of the weight-gradient kernel (32 measured 4 % slower)
 
@@ -874,97 +844,6 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int chunks, 
 }
 
 // -------------------------------------------------------------------------- host side
-static int validate(const svae_conv_desc* d) {
-  SVAE_REQUIRE(d != nullptr, SVAE_ERR_ARG, "conv: null descriptor");
-  SVAE_REQUIRE(d->batch > 0 && d->l_in > 0 && d->l_out > 0, SVAE_ERR_SHAPE, "conv: non-positive batch/length");
-  SVAE_REQUIRE(d->c_in > 0 && d->c_out > 0 && d->c_in % 16 == 0 && d->c_out % 16 == 0, SVAE_ERR_SHAPE,
-               "conv: padded channel counts must be positive multiples of 16 (got %d,%d)", d->c_in, d->c_out);
-  SVAE_REQUIRE(d->ld_in >= d->c_in && d->ld_out >= d->c_out && d->ld_in % 4 == 0 && d->ld_out % 4 == 0, SVAE_ERR_ALIGN,
-               "conv: leading dimensions must be >= channels and multiples of 4");
-  SVAE_REQUIRE(d->kernel >= 1 && d->kernel <= SVAE_MAX_TAPS, SVAE_ERR_SHAPE, "conv: kernel %d not in [1,%d]", d->kernel,
-               SVAE_MAX_TAPS);
-  SVAE_REQUIRE(d->stride == 1 || d->stride == 2, SVAE_ERR_SHAPE, "conv: stride %d unsupported", d->stride);
-  SVAE_REQUIRE(d->dilation >= 1 && d->padding >= 0, SVAE_ERR_SHAPE, "conv: bad dilation/padding");
-  int expect;
-  if (!d->transposed)
-    expect = (d->l_in + 2 * d->padding - d->dilation * (d->kernel - 1) - 1) / d->stride + 1;
-  else
-    expect = (d->l_in - 1) * d->stride - 2 * d->padding + d->dilation * (d->kernel - 1) + 1;
-  SVAE_REQUIRE(expect == d->l_out, SVAE_ERR_SHAPE, "conv: l_out %d != formula %d", d->l_out, expect);
-  return SVAE_OK;
-}
-
-// Build the gather plan.  strided=true: src = j*stride + t*dil - pad (one phase);
-// strided=false: src = (dst + pad - t*dil)/stride, split by dst parity.
-static void build_plan(GatherArgs& g, const svae_conv_desc* d, bool strided, int Ldst, int Lsrc) {
-  g.Lin = Lsrc;
-  g.Lout = Ldst;
-  for (int p = 0; p < 2; ++p) { g.nj[p] = 0; g.ntaps[p] = 0; g.M[p] = 0; g.blocks_m[p] = 0; }
-  if (strided) {
-    g.n_phase = 1;
-    g.sj = d->stride;
-    g.nj[0] = Ldst;
-    g.ntaps[0] = d->kernel;
-    for (int t = 0; t < d->kernel; ++t) { g.base[0][t] = t * d->dilation - d->padding; g.widx[0][t] = t; }
-  } else {
-    const int s = d->stride;
-    g.n_phase = s;
-    g.sj = 1;
-    for (int p = 0; p < s; ++p) {
-      g.nj[p] = (Ldst - p + s - 1) / s;
-      if (g.nj[p] < 0) g.nj[p] = 0;
-      int n = 0;
-      for (int t = 0; t < d->kernel; ++t) {
-        const int num = p + d->padding - t * d->dilation;
-        if (((num % s) + s) % s != 0) continue;
-        g.base[p][n] = num / s;  // exact division
-        g.widx[p][n] = t;
-        ++n;
-      }
-      g.ntaps[p] = n;
-    }
-  }
-  for (int p = 0; p < g.n_phase; ++p) g.M[p] = (long long)d->batch * g.nj[p];
-}
-
-// ---- tile selection.  Per-block work is MFMA-bound and co-resident blocks hide each other's
-// barrier / LDS-fill stalls, so prefer the largest tile that still gives >= 2 blocks per CU;
-// below that, more (smaller) blocks win.  Scores are relative throughput estimates.
-struct Tile { int bm, bn; int dma = 0; };
-
-static double tile_score(long long M0, long long M1, int N, int bm, int bn) {
-  const long long bmk = (M0 + bm - 1) / bm + (M1 + bm - 1) / bm;
-  const long long bnk = (N + bn - 1) / bn;
-  const long long blocks = bmk * bnk;
-  if (blocks == 0) return 0.0;
-  const double useful = (double)(M0 + M1) * N / ((double)bmk * bm * bnk * bn);
-  const double resident = 256.0 * (bm * bn >= 128 * 128 ? 2.0 : 3.0);  // blocks the chip holds at once
-  const double waves = (double)((blocks + (long long)resident - 1) / (long long)resident);
-  const double fill = (double)blocks / (waves * resident);
-  const double occ = blocks >= 512 ? 1.0 : (blocks >= 256 ? 0.8 : 0.8 * blocks / 256.0);
-  const double teff = (bm * bn >= 128 * 128) ? 1.0 : (bm * bn >= 64 * 128 ? 0.93 : 0.85);
-  return useful * teff * occ * (0.5 + 0.5 * fill);
-}
-
-static Tile pick_tile(long long M0, long long M1, int N) {
-  const Tile cand[4] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-  Tile best = cand[0];
-  double bs = -1.0;
-  for (const Tile& t : cand) {
-    const double sc = tile_score(M0, M1, N, t.bm, t.bn);
-    if (sc > bs * 1.001) { bs = sc; best = t; }
-  }
-  return best;
-}
-
-static bool decode_tile(int code, Tile& t) {
-  if (code <= 0) return false;
-  t.dma = code >= 1000000 ? 1 : 0;  // 1BBBNNN: LDS-DMA staging variant of the gather kernel
-  code %= 1000000;
-  t.bm = code / 1000;
-  t.bn = code % 1000;
-  return (t.bm == 64 || t.bm == 128) && (t.bn == 64 || t.bn == 128);
-}
 
 template <bool B_KC>
 static int launch_gather_auto(GatherArgs& g, hipStream_t st, int override_code) {
@@ -1090,8 +969,8 @@ extern "C" size_t svae_conv_wgrad_workspace(const svae_conv_desc* d) {
   return (slab + (size_t)chunks * d->c_out) * sizeof(float) + 256;
 }
 
-extern "C" int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
-                               size_t ws_bytes, int accumulate, void* stream) {
+static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
+                           size_t ws_bytes, int accumulate, void* stream, int pieces) {
   if (int e = validate(d)) return e;
   SVAE_REQUIRE(x && dy && dw, SVAE_ERR_ARG, "conv_wgrad: null pointer");
   SVAE_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(ws), SVAE_ERR_ALIGN,
@@ -1120,7 +999,10 @@ extern "C" int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const fl
   float* slab = (float*)ws;
   if (nsplit > 1) { g.out = slab; g.slab_stride = wsize; g.accumulate = 0; }
   else { g.out = dw; g.slab_stride = 0; g.accumulate = accumulate; }
-  if (wg.fused) {
+  if (pieces > 0) {
+    dim3 grid(d->kernel * g.ctiles, (d->c_out + wg.bn - 1) / wg.bn, nsplit);
+    if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces)) return e;
+  } else if (wg.fused) {
     WgradFusedArgs f;
     memset(&f, 0, sizeof(f));
     f.R = wg.R; f.rows_per_split = wg.rps; f.nj = wg.nj;
@@ -1170,6 +1052,20 @@ extern "C" int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const fl
   return SVAE_OK;
 }
 
+extern "C" int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
+                               size_t ws_bytes, int accumulate, void* stream) {
+  return conv_wgrad_impl(d, x, dy, dw, db, ws, ws_bytes, accumulate, stream, 0);
+}
+
+// same contract, products on the bf16 matrix cores with `pieces` bf16 pieces per operand (gemm_bf16s.hip);
+// d->tile[2] must not select the tap-fused variant
+extern "C" int svae_conv_wgrad_split(const svae_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
+                                     size_t ws_bytes, int accumulate, int pieces, void* stream) {
+  SVAE_REQUIRE(pieces >= 1 && pieces <= 3, SVAE_ERR_ARG, "conv_wgrad_split: pieces %d not in 1..3", pieces);
+  SVAE_REQUIRE(d == nullptr || d->tile[2] != 1, SVAE_ERR_ARG, "conv_wgrad_split: the tap-fused tile code is fp32 only");
+  return conv_wgrad_impl(d, x, dy, dw, db, ws, ws_bytes, accumulate, stream, pieces);
+}
+
 // which tile the dispatcher picks for this problem (bench.py names the kernel template with it)
 extern "C" int svae_conv_tile(const svae_conv_desc* d, int kind, int* bm, int* bn) {
   if (int e = validate(d)) return e;
@@ -1186,7 +1082,7 @@ extern "C" int svae_conv_tile(const svae_conv_desc* d, int kind, int* bm, int* b
   else { g.N = d->c_in; build_plan(g, d, d->transposed != 0, d->l_in, d->l_out); }
   Tile t;
   if (!decode_tile(d->tile[kind], t)) t = pick_tile(g.M[0], g.M[1], g.N);
-  *bm = t.dma ? t.bm + 1000 : t.bm;  // +1000: LDS-DMA staging variant
+  *bm = t.bm + 1000 * t.dma;  // + 1000 * kernel variant (fp32: 1 = LDS-DMA staging)
   *bn = t.bn;
   return SVAE_OK;
 }

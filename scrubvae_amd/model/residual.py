@@ -574,6 +574,7 @@ class ResVAE(nn.Module):
     # ------------------------------------------------------------------ reference API
     def encode(self, data):
         """ResVAE.encode (residual.py:438-459): returns {"mu": [B,z], "L": [B,z,z]}."""
+        ops.bump_weight_epoch()
         B, flat, h = self._encode_trunk(data)
         mu, sigma, zc, klp = self._heads(B, h, None)
         self._state = dict(B=B, flat=flat, h=h, eps=None)
@@ -581,6 +582,7 @@ class ResVAE(nn.Module):
 
     def decode(self, z, data):
         """ResVAE.decode (residual.py:461-491)."""
+        ops.bump_weight_epoch()
         B = z.shape[0]
         zcp = pad16(self.z_dim + self.conditional_dim)
         zc = self._buf("dec.zc", (B, zcp), zero=True)
@@ -604,6 +606,7 @@ class ResVAE(nn.Module):
     def forward(self, data):
         """VAE.forward (residual.py:318-362).  Returns data_o with mu, L, z, x6d, root, var,
         disentangle[method][feature]."""
+        ops.bump_weight_epoch()  # split-bf16 weight copies (if any) are refreshed on first use in this pass
         B, flat, h = self._encode_trunk(data)
         eps = None
         if self.training:

@@ -81,6 +81,36 @@ _WGRAD_CODES = _TILES + (1,)  # 1 = tap-fused small-weight kernel
 
 _KIND_ID = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 
+# Arithmetic of the large contractions.  "f32": v_mfma_f32_32x32x2_f32.  "bf16x6" / "bf16x3" /
+# "bf16": every fp32 operand is split into 3 / 2 / 1 bf16 pieces and the 6 / 3 / 1 leading cross
+# products run on the bf16 matrix cores with fp32 accumulation (csrc/gemm_bf16s.hip); bf16x6
+# is as accurate as f32.  Read when a Conv is constructed; convs below SPLIT_MIN_FLOPS stay f32.
+PRECISION = os.environ.get("SVAE_PRECISION", "f32")
+_PIECES = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1}
+SPLIT_MIN_FLOPS = float(os.environ.get("SVAE_SPLIT_MIN_FLOPS", 2e8))
+# VBBBNNN: V = 0: 4 waves, double-buffered LDS; 1: 4 waves, one LDS buffer; 2 / 3: 8 waves (BM = 128), one / two buffers
+# 4: wave-specialised (4 producer + 8 consumer waves); 5: wave-specialised 4 + 4
+_SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2128064, 3128128, 3128064)
+                       + (4128128, 4128064, 4064128) + tuple(5000000 + c for c in _TILES)
+                       + (6128128, 6128064, 6064128) + tuple(7000000 + c for c in _TILES))
+_SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2, 1"}
+_SPLIT_WGRAD_CODES = _TILES
+MIX_F32 = True  # a bf16x6 conv may keep the fp32 MFMA kernel for a pass where that is faster (same accuracy)
+WEIGHT_EPOCH = 0  # bumped whenever master weights may have changed (start of every model pass)
+
+
+def set_precision(name):
+    global PRECISION
+    if name not in _PIECES:
+        raise ValueError(f"precision {name!r} not in {sorted(_PIECES)}")
+    PRECISION = name
+
+
+def bump_weight_epoch():
+    """Invalidate the split-bf16 weight copies: the next use of each Conv re-splits its weights."""
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
 
 def _timed(kind, conv, n_padded, fn):
     t = TIMER
@@ -98,7 +128,7 @@ class Conv:
     """Geometry of one nn.Conv1d / nn.ConvTranspose1d / nn.Linear call (padded channels)."""
 
     def __init__(self, batch, l_in, c_in, c_out, kernel, stride=1, padding=0, dilation=1, transposed=False,
-                 ld_in=None, ld_out=None):
+                 ld_in=None, ld_out=None, pieces=None):
         self.c_in, self.c_out = c_in, c_out
         self.c_in_p, self.c_out_p = pad16(c_in), pad16(c_out)
         if transposed:
@@ -114,27 +144,54 @@ class Conv:
         # algorithmic FLOPs of one pass (forward = dgrad = wgrad): 2*B*L*k*Cin*Cout with the
         # unpadded channel counts, L = output length (conv) / input length (transposed conv)
         self.flops = 2.0 * batch * (l_in if transposed else l_out) * kernel * c_in * c_out
+        # bf16 pieces per operand (0 = fp32 MFMA kernels)
+        self.pieces = (_PIECES[PRECISION] if self.flops >= SPLIT_MIN_FLOPS else 0) if pieces is None else int(pieces)
+        self._wsplit, self._split_epoch, self._split_src = None, -1, None
+
+    def split_weights(self, w):
+        """bf16 piece planes of `w` for the split kernels; re-split once per weight epoch."""
+        if self._split_epoch != WEIGHT_EPOCH or self._split_src != w.data_ptr():
+            if self._wsplit is None:
+                n = int(_lib.lib().svae_conv_split_bytes(C.byref(self.desc)))
+                self._wsplit = torch.empty(n + 64, dtype=torch.uint8, device=w.device)
+            check(_lib.lib().svae_conv_split_weights(C.byref(self.desc), _p(w), _p(self._wsplit), _stream()), "conv_split_weights")
+            self._split_epoch, self._split_src = WEIGHT_EPOCH, w.data_ptr()
+        return self._wsplit
+
+    _F32_FLAG = 100000000  # table / log encoding: "this kind of this split-precision conv runs the fp32 kernel <code % flag>"
+
+    def _kind_pieces(self, kind):
+        return self.__dict__.get("_kp", {}).get(kind, self.pieces)
+
+    def _set_choice(self, kind, pieces, code):
+        self.__dict__.setdefault("_kp", {})[kind] = pieces
+        self.desc.tile[_KIND_ID[kind]] = code
+        self._ws_bytes = None
+        self.__dict__.pop("_names", None)
 
     def _tune(self, kind, run):
-        """run(): launches this conv once with scratch outputs.  Picks desc.tile[kind]."""
-        k = _KIND_ID[kind]
+        """run(): launches this conv once with scratch outputs.  Picks the kernel family (for a
+        bf16x6 conv: split-bf16 or fp32 MFMA -- both are fp32-accurate) and desc.tile[kind]."""
         tuned = self.__dict__.setdefault("_tuned", set())
         if kind in tuned:
             return
         tuned.add(kind)
         d = self.desc
-        key = f"{kind}:{d.batch}:{d.l_in}:{d.c_in}:{d.c_out}:{d.ld_in}:{d.ld_out}:{d.kernel}:{d.stride}:{d.padding}:{d.transposed}"
+        key = f"{kind}{'@' + str(self.pieces) if self.pieces else ''}:{d.batch}:{d.l_in}:{d.c_in}:{d.c_out}:{d.ld_in}:{d.ld_out}:{d.kernel}:{d.stride}:{d.padding}:{d.transposed}"
         if key in TILE_TABLE:
-            self.desc.tile[k] = int(TILE_TABLE[key])
-            self._ws_bytes = None
-            self.__dict__.pop("_names", None)
+            v = int(TILE_TABLE[key])
+            self._set_choice(kind, 0 if v >= self._F32_FLAG else self.pieces, v % self._F32_FLAG)
             return
         if not AUTOTUNE or self.flops < AUTOTUNE_MIN_FLOPS or torch.cuda.is_current_stream_capturing():
             return
-        best, best_t = 0, float("inf")
-        for code in (_WGRAD_CODES if kind == "wgrad" else _GATHER_CODES):
-            self.desc.tile[k] = code
-            self._ws_bytes = None
+        cands = []
+        if self.pieces:
+            cands += [(self.pieces, c) for c in (_SPLIT_WGRAD_CODES if kind == "wgrad" else _SPLIT_GATHER_CODES)]
+        if not self.pieces or (self.pieces == 3 and MIX_F32):
+            cands += [(0, c) for c in (_WGRAD_CODES if kind == "wgrad" else _GATHER_CODES)]
+        best, best_t = (self.pieces, 0), float("inf")
+        for pieces, code in cands:
+            self._set_choice(kind, pieces, code)
             try:
                 run()  # warm-up (also validates the workspace size for this tile)
             except RuntimeError:
@@ -148,11 +205,9 @@ class Conv:
                 e.synchronize()
                 t = min(t, s.elapsed_time(e))
             if t < best_t * 0.98:  # candidates are ordered large -> small: ties keep the larger tile
-                best, best_t = code, t
-        self.desc.tile[k] = best
-        TUNED_LOG[key] = best
-        self._ws_bytes = None
-        self.__dict__.pop("_names", None)
+                best, best_t = (pieces, code), t
+        self._set_choice(kind, *best)
+        TUNED_LOG[key] = best[1] + (self._F32_FLAG if (self.pieces and not best[0]) else 0)
 
     def kernel_name(self, kind):
         """Name of the kernel template instance this call dispatches to (as rocprofv3 prints it)."""
@@ -160,7 +215,17 @@ class Conv:
         if kind not in names:
             bm, bn = C.c_int(), C.c_int()
             check(_lib.lib().svae_conv_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn)), "conv_tile")
-            if kind == "wgrad":
+            kp = self._kind_pieces(kind)
+            if kp and kind == "wgrad":
+                names[kind] = f"wgrad_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}>"
+            elif kp:
+                v = bm.value // 1000 if self.desc.tile[_KIND_ID[kind]] > 0 else 1
+                if v >= 4:
+                    cw = "2, 2" if v in (5, 7) else ("4, 2" if bm.value % 1000 == 128 else "2, 4")
+                    names[kind] = f"gather_gemm_bf16s_ws_kernel<{bm.value % 1000}, {bn.value}, {kp}, {cw}, {2 if v < 6 else 3}>"
+                else:
+                    names[kind] = f"gather_gemm_bf16s_kernel<{bm.value % 1000}, {bn.value}, {kp}, {_SPLIT_VARIANT[v]}>"
+            elif kind == "wgrad":
                 names[kind] = (f"wgrad_fused_kernel<{-bm.value}, {'false' if self.desc.transposed else 'true'}>" if bm.value < 0
                                else f"wgrad_gemm_kernel<{bm.value}, {bn.value}>")
             else:
@@ -185,22 +250,41 @@ class Conv:
             self._ws_bytes = int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc)))
         return self._ws_bytes
 
+    def _launch_fwd(self, x, w, bias, y, acc):
+        kp = self._kind_pieces("fwd")
+        if kp:
+            return check(_lib.lib().svae_conv_fwd_split(C.byref(self.desc), _p(x), _p(self.split_weights(w)), _p(bias), _p(y),
+                                                         acc, kp, _stream()), "conv_fwd_split")
+        return check(_lib.lib().svae_conv_fwd(C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), acc, _stream()), "conv_fwd")
+
+    def _launch_dgrad(self, dy, w, dx, acc):
+        kp = self._kind_pieces("dgrad")
+        if kp:
+            return check(_lib.lib().svae_conv_dgrad_split(C.byref(self.desc), _p(dy), _p(self.split_weights(w)), _p(dx),
+                                                           acc, kp, _stream()), "conv_dgrad_split")
+        return check(_lib.lib().svae_conv_dgrad(C.byref(self.desc), _p(dy), _p(w), _p(dx), acc, _stream()), "conv_dgrad")
+
+    def _launch_wgrad(self, x, dy, dw, db, ws, acc):
+        nbytes = ws.numel() * ws.element_size()
+        kp = self._kind_pieces("wgrad")
+        if kp:
+            return check(_lib.lib().svae_conv_wgrad_split(C.byref(self.desc), _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes,
+                                                           acc, kp, _stream()), "conv_wgrad_split")
+        return check(_lib.lib().svae_conv_wgrad(C.byref(self.desc), _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, acc,
+                                                 _stream()), "conv_wgrad")
+
     def fwd(self, x, w, bias, y, accumulate=False):
         if "fwd" not in self.__dict__.get("_tuned", ()):
             scratch = torch.empty(self.batch * self.l_out * self.desc.ld_out + 16, device=x.device)
-            self._tune("fwd", lambda: check(_lib.lib().svae_conv_fwd(
-                C.byref(self.desc), _p(x), _p(w), _p(bias), _p(scratch), 0, _stream()), "conv_fwd(tune)"))
-        _timed("fwd", self, self.c_out_p, lambda: check(_lib.lib().svae_conv_fwd(
-            C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), int(accumulate), _stream()), "conv_fwd"))
+            self._tune("fwd", lambda: self._launch_fwd(x, w, bias, scratch, 0))
+        _timed("fwd", self, self.c_out_p, lambda: self._launch_fwd(x, w, bias, y, int(accumulate)))
         return y
 
     def dgrad(self, dy, w, dx, accumulate=False):
         if "dgrad" not in self.__dict__.get("_tuned", ()):
             scratch = torch.empty(self.batch * self.l_in * self.desc.ld_in + 16, device=dy.device)
-            self._tune("dgrad", lambda: check(_lib.lib().svae_conv_dgrad(
-                C.byref(self.desc), _p(dy), _p(w), _p(scratch), 0, _stream()), "conv_dgrad(tune)"))
-        _timed("dgrad", self, self.c_in_p, lambda: check(_lib.lib().svae_conv_dgrad(
-            C.byref(self.desc), _p(dy), _p(w), _p(dx), int(accumulate), _stream()), "conv_dgrad"))
+            self._tune("dgrad", lambda: self._launch_dgrad(dy, w, scratch, 0))
+        _timed("dgrad", self, self.c_in_p, lambda: self._launch_dgrad(dy, w, dx, int(accumulate)))
         return dx
 
     def wgrad(self, x, dy, dw, db, ws, accumulate=False):
@@ -214,14 +298,11 @@ class Conv:
                 need = max(need, int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc))))
             self.desc.tile[2] = 0
             sws = torch.empty(need // 4 + 16, device=x.device)
-            self._tune("wgrad", lambda: check(_lib.lib().svae_conv_wgrad(
-                C.byref(self.desc), _p(x), _p(dy), _p(sdw), _p(sdb), _p(sws), sws.numel() * 4, 0, _stream()), "conv_wgrad(tune)"))
+            self._tune("wgrad", lambda: self._launch_wgrad(x, dy, sdw, sdb, sws, 0))
             if ws.numel() * ws.element_size() < self.wgrad_workspace_bytes():
                 raise RuntimeError("conv_wgrad: workspace smaller than the tuned tile needs; size it with "
                                    "Conv.wgrad_workspace_bytes() AFTER the first call or use ops.max_wgrad_workspace()")
-        _timed("wgrad", self, self.c_out_p, lambda: check(_lib.lib().svae_conv_wgrad(
-            C.byref(self.desc), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel() * ws.element_size(), int(accumulate),
-            _stream()), "conv_wgrad"))
+        _timed("wgrad", self, self.c_out_p, lambda: self._launch_wgrad(x, dy, dw, db, ws, int(accumulate)))
 
 
 # ----------------------------------------------------------------- weight layout (TIO)

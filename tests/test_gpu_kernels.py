@@ -375,3 +375,96 @@ def test_gather_kernel_variants(ops, case, code):
     dxd = torch.full((B * L, cv.c_in_p), float("nan"), device="cuda")
     cv.dgrad(to_nlc(dy), wd, dxd)
     assert relerr(from_nlc(dxd, B, L, Cin), x.grad) < 2e-6 * math.sqrt(Cout * k) + 2e-6
+
+
+# ------------------------------------------------------------------ split-bf16 GEMM kernels
+_SPLIT_TOL = {3: 2e-6, 2: 6e-5, 1: 1.2e-2}  # per sqrt(K): pieces=3 is held to the fp32 kernels' bound
+
+
+def _split_cases():
+    out = []
+    for case in CONV_CASES:
+        for code in (128128, 64128, 128064, 64064, 1128128, 1064128, 1128064, 1064064, 2128128, 2128064, 3128128, 3128064,
+                     4128128, 4128064, 4064128, 5128128, 5128064, 5064128, 5064064,
+                     6128128, 6128064, 6064128, 7128128, 7128064, 7064128, 7064064, 0):
+            out.append((case, code, 3))
+        out.append((case, 64064, 2))
+        out.append((case, 2128064, 2))
+        out.append((case, 1128064, 1))
+    return out
+
+
+@pytest.mark.parametrize("case,code,pieces", _split_cases())
+def test_split_gather_kernels(ops, case, code, pieces):
+    """Forward / data-gradient on the bf16 matrix cores with 3 / 2 / 1 bf16 pieces per operand
+    (csrc/gemm_bf16s.hip) against torch fp64; 3 pieces must meet the fp32 kernels' tolerance."""
+    B, L, Cin, Cout, k, s, p, tr = case
+    g = torch.Generator().manual_seed(11 + sum(case[:7]))
+    x = torch.randn(B, Cin, L, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(*((Cin, Cout, k) if tr else (Cout, Cin, k)), generator=g, dtype=torch.float64) / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    y = (F.conv_transpose1d if tr else F.conv1d)(x, w, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    cv = ops.Conv(B, L, Cin, Cout, k, s, p, 1, tr, pieces=pieces)
+    cv.__dict__["_tuned"] = {"fwd", "dgrad", "wgrad"}
+    cv.desc.tile[0] = cv.desc.tile[1] = code
+    ops.bump_weight_epoch()
+    wd = ops.conv_weight_to_tio(w.float(), tr).cuda().contiguous()
+    bd = torch.zeros(cv.c_out_p); bd[:Cout] = b.float(); bd = bd.cuda()
+    yd = torch.full((B * cv.l_out, cv.c_out_p), float("nan"), device="cuda")
+    tol = _SPLIT_TOL[pieces]
+    cv.fwd(to_nlc(x.detach()), wd, bd, yd)
+    assert relerr(from_nlc(yd, B, cv.l_out, Cout), y.detach()) < tol * math.sqrt(Cin * k) + tol
+    assert float(yd[:, Cout:].abs().max() if cv.c_out_p > Cout else 0) == 0.0
+    cv.fwd(to_nlc(x.detach()), wd, bd, yd, accumulate=True)
+    assert relerr(from_nlc(yd, B, cv.l_out, Cout), 2 * y.detach()) < tol * math.sqrt(Cin * k) + tol
+    dxd = torch.full((B * L, cv.c_in_p), float("nan"), device="cuda")
+    cv.dgrad(to_nlc(dy), wd, dxd)
+    assert relerr(from_nlc(dxd, B, L, Cin), x.grad) < tol * math.sqrt(Cout * k) + tol
+    assert not torch.isnan(dxd).any()
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("code,pieces", [(128128, 3), (64128, 3), (128064, 3), (64064, 3), (0, 3), (64064, 2), (128064, 1)])
+def test_split_wgrad_kernels(ops, case, code, pieces):
+    B, L, Cin, Cout, k, s, p, tr = case
+    g = torch.Generator().manual_seed(13 + sum(case[:7]))
+    x = torch.randn(B, Cin, L, generator=g, dtype=torch.float64)
+    w = (torch.randn(*((Cin, Cout, k) if tr else (Cout, Cin, k)), generator=g, dtype=torch.float64)).requires_grad_(True)
+    y = (F.conv_transpose1d if tr else F.conv1d)(x, w, None, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    cv = ops.Conv(B, L, Cin, Cout, k, s, p, 1, tr, pieces=pieces)
+    cv.__dict__["_tuned"] = {"fwd", "dgrad", "wgrad"}
+    cv.desc.tile[2] = code
+    cv._ws_bytes = None
+    xd, dyd = to_nlc(x), to_nlc(dy)
+    ws = torch.empty(cv.wgrad_workspace_bytes() // 4 + 4, device="cuda")
+    dwd = torch.full(cv.weight_shape, float("nan"), device="cuda")
+    dbd = torch.full((cv.c_out_p,), float("nan"), device="cuda")
+    cv.wgrad(xd, dyd, dwd, dbd, ws)
+    tol = _SPLIT_TOL[pieces]
+    bound = tol * math.sqrt(B * y.shape[-1]) + tol
+    assert relerr(ops.conv_weight_from_tio(dwd.cpu(), Cin, Cout, tr), w.grad) < bound
+    assert not torch.isnan(dwd).any()
+    cv.wgrad(xd, dyd, dwd, dbd, ws, accumulate=True)
+    assert relerr(ops.conv_weight_from_tio(dwd.cpu(), Cin, Cout, tr), 2 * w.grad) < bound
+
+
+def test_split_weight_copies_follow_the_epoch(ops):
+    """The bf16 weight pieces are refreshed when the weight epoch is bumped, not before."""
+    cv = ops.Conv(4, 16, 32, 32, 5, 1, 2, pieces=3)
+    cv.__dict__["_tuned"] = {"fwd", "dgrad", "wgrad"}
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4 * 16, 32, generator=g).cuda()
+    w = torch.randn(5, 32, 32, generator=g).cuda()
+    y0 = torch.empty(4 * 16, 32, device="cuda"); y1 = torch.empty_like(y0); y2 = torch.empty_like(y0)
+    ops.bump_weight_epoch()
+    cv.fwd(x, w, None, y0)
+    w.mul_(2.0)
+    cv.fwd(x, w, None, y1)          # same epoch: stale pieces by contract
+    ops.bump_weight_epoch()
+    cv.fwd(x, w, None, y2)
+    assert torch.equal(y0, y1)
+    assert relerr(y2, 2 * y0) < 1e-6

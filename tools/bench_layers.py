@@ -6,6 +6,9 @@ import torch
 from scrubvae_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+if len(sys.argv) > 2:
+    ops.set_precision(sys.argv[2])  # f32 | bf16x6 | bf16x3 | bf16
+    ops.TILE_TABLE = {k: v for k, v in ops.TILE_TABLE.items() if "@" in k.split(":")[0]}
 J = 23
 C = 6 * J + 3
 ch = [64, 128, 256, 512, 1024]
@@ -49,6 +52,7 @@ for name, l_in, cin, cout, k, s, p, tr in layers:
     for kk, tt in zip(("fwd", "dgrad", "wgrad"), t):
         tot[kk][0] += cv.flops; tot[kk][1] += tt
     M = B * (l_in if tr else cv.l_out)
-    print(f"      {name:12s} {M:7d} {k*cin:6d} {cout:5d} | " + " | ".join(f"{cv.flops/tt/1e12:6.1f} {tt*1e6:6.0f}" for tt in t))
+    codes = "/".join(str(cv.desc.tile[i]) for i in range(3))
+    print(f"      {name:12s} {M:7d} {k*cin:6d} {cout:5d} | " + " | ".join(f"{cv.flops/tt/1e12:6.1f} {tt*1e6:6.0f}" for tt in t) + f"   {codes}")
 for kk, (f, tt) in tot.items():
     print(f"TOTAL {kk}: {f/1e9:.1f} GFLOP in {tt*1e3:.2f} ms = {f/tt/1e12:.1f} TFLOP/s ({f/tt/1e12/157.3*100:.0f}% of fp32 MFMA peak)")
