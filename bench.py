@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--full", action="store_true", help="configs[2]: conditional + grad-reversal + adversarial heads")
     ap.add_argument("--local-bn", action="store_true", help="per-rank BatchNorm statistics (no sync-BN collectives)")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph (single GPU)")
-    ap.add_argument("--precision", default=os.environ.get("SVAE_PRECISION", "f32"), choices=list(PRODUCTS),
+    ap.add_argument("--precision", default=os.environ.get("SVAE_PRECISION", "bf16x6"), choices=list(PRODUCTS),
                     help="arithmetic of the large contractions: f32 = fp32 MFMA; bf16x6 = fp32-accurate 3-piece split on the bf16 "
                          "matrix cores (6 products); bf16x3 / bf16 = 2 / 1 pieces (reduced accuracy, not a headline mode)")
     ap.add_argument("--serial-streams", action="store_true",

@@ -622,12 +622,14 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 constexpr int WSK = 16;
 constexpr int WROWB = 48;
 
-template <int BM, int BN, int P>
+// NSTAGE = 2: double-buffered LDS, one barrier per stage;  NSTAGE = 1: one buffer, two barriers, half the LDS
+// (more workgroups per CU overlap each other's conversion / LDS / MFMA phases)
+template <int BM, int BN, int P, int NSTAGE>
 __global__ __launch_bounds__(256, 2) void wgrad_gemm_bf16s_kernel(const WgradArgs g) {
   constexpr int WM = BM / 2, MT = WM / 32, WN = BN / 2, NT = WN / 32;
   constexpr int A_PIECE = BM * WROWB, B_PIECE = BN * WROWB;
   constexpr int STAGE = P * (A_PIECE + B_PIECE);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
 
   const int tid = threadIdx.x;
   const int ti = blockIdx.x / g.ctiles;
@@ -720,14 +722,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_bf16s_kernel(const WgradArg
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (int)((r_end - r_begin + WSK - 1) / WSK);
-  if (nk > 0) {
-    load_tile();
-    store_tile(0);
-    if (nk > 1) load_tile();
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const unsigned char* st = smem + (kt & 1) * STAGE;
+  auto compute = [&](const unsigned char* st, auto mid) {
     uint4 av[MT][P], bv[NT][P];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -739,13 +734,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_bf16s_kernel(const WgradArg
 #pragma unroll
       for (int p = 0; p < P; ++p)
         bv[nt][p] = *reinterpret_cast<const uint4*>(st + P * A_PIECE + p * B_PIECE + (wc * WN + nt * 32 + lr) * WROWB + h * 16);
-    if (kt + 1 < nk) store_tile((kt & 1) ^ 1);
-    if (kt + 2 < nk) load_tile();
+    mid();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_split<P>(av[mt], bv[nt], acc[mt][nt]);
+  };
+  // loads / stores past the last tile are unconditional on purpose (rows past r_end read the
+  // operand base and stage zeros into a buffer nobody reads): conditional loads make hipcc wait
+  // vmcnt(0) and lose the prefetch distance
+  if constexpr (NSTAGE == 2) {
+    load_tile();
+    store_tile(0);
+    load_tile();
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      compute(smem + (kt & 1) * STAGE, [&]() {
+        store_tile((kt & 1) ^ 1);
+        load_tile();
+      });
+      __syncthreads();
+    }
+  } else {
+    load_tile();
+    for (int kt = 0; kt < nk; ++kt) {
+      store_tile(0);
+      __syncthreads();
+      load_tile();
+      compute(smem, []() {});
+      __syncthreads();
+    }
   }
 
   float* out = g.out + (long long)blockIdx.z * g.slab_stride + (long long)ti * g.Kc * g.ldW;
@@ -769,18 +787,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_bf16s_kernel(const WgradArg
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NSTAGE>
 static void launch_wgrad_p(const WgradArgs& g, dim3 grid, hipStream_t st, int pieces) {
-  if (pieces == 3) hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 3>), grid, dim3(256), 0, st, g);
-  else if (pieces == 2) hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 2>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 1>), grid, dim3(256), 0, st, g);
+  if (pieces == 3) hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 3, NSTAGE>), grid, dim3(256), 0, st, g);
+  else if (pieces == 2) hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 2, NSTAGE>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 1, NSTAGE>), grid, dim3(256), 0, st, g);
 }
 
-int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int pieces) {
-  if (bm == 128 && bn == 128) launch_wgrad_p<128, 128>(g, grid, st, pieces);
-  else if (bm == 128 && bn == 64) launch_wgrad_p<128, 64>(g, grid, st, pieces);
-  else if (bm == 64 && bn == 128) launch_wgrad_p<64, 128>(g, grid, st, pieces);
-  else launch_wgrad_p<64, 64>(g, grid, st, pieces);
+// variant 0: double-buffered LDS; 1: single LDS buffer
+int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int pieces, int variant) {
+#define SVAE_WG_CASE(BM_, BN_)                                            \
+  if (bm == BM_ && bn == BN_) {                                           \
+    if (variant == 1) launch_wgrad_p<BM_, BN_, 1>(g, grid, st, pieces);   \
+    else launch_wgrad_p<BM_, BN_, 2>(g, grid, st, pieces);                \
+  }
+  SVAE_WG_CASE(128, 128) else SVAE_WG_CASE(128, 64) else SVAE_WG_CASE(64, 128) else SVAE_WG_CASE(64, 64)
+#undef SVAE_WG_CASE
   return check_launch("wgrad_gemm_bf16s");
 }
 

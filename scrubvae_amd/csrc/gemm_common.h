@@ -130,6 +130,6 @@ struct WgradArgs {
 };
 
 // split-bf16 weight-gradient main kernel (gemm_bf16s.hip); same grid / slabs as wgrad_gemm_kernel
-int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int pieces);
+int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int pieces, int variant);
 
 }  // namespace svae

@@ -1001,7 +1001,7 @@ static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float*
   else { g.out = dw; g.slab_stride = 0; g.accumulate = accumulate; }
   if (pieces > 0) {
     dim3 grid(d->kernel * g.ctiles, (d->c_out + wg.bn - 1) / wg.bn, nsplit);
-    if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces)) return e;
+    if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces, d->tile[2] / 1000000)) return e;
   } else if (wg.fused) {
     WgradFusedArgs f;
     memset(&f, 0, sizeof(f));

@@ -94,7 +94,7 @@ _SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2
                        + (4128128, 4128064, 4064128) + tuple(5000000 + c for c in _TILES)
                        + (6128128, 6128064, 6064128) + tuple(7000000 + c for c in _TILES))
 _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2, 1"}
-_SPLIT_WGRAD_CODES = _TILES
+_SPLIT_WGRAD_CODES = _TILES + tuple(1000000 + c for c in _TILES)  # 1BBBNNN: single LDS buffer
 MIX_F32 = True  # a bf16x6 conv may keep the fp32 MFMA kernel for a pass where that is faster (same accuracy)
 WEIGHT_EPOCH = 0  # bumped whenever master weights may have changed (start of every model pass)
 
@@ -217,7 +217,7 @@ class Conv:
             check(_lib.lib().svae_conv_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn)), "conv_tile")
             kp = self._kind_pieces(kind)
             if kp and kind == "wgrad":
-                names[kind] = f"wgrad_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}>"
+                names[kind] = f"wgrad_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}, {1 if self.desc.tile[2] >= 1000000 else 2}>"
             elif kp:
                 v = bm.value // 1000 if self.desc.tile[_KIND_ID[kind]] > 0 else 1
                 if v >= 4:

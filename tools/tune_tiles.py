@@ -11,7 +11,10 @@ from scrubvae_amd.train.losses import get_batch_loss
 ops.TILE_TABLE = {}
 ops.AUTOTUNE_REPS = 12
 table = {}
-for joints, batch, full in ((23, 1024, False), (23, 1024, True), (23, 4096, False), (18, 1024, False), (23, 256, False)):
+PRECISIONS = sys.argv[1:] or ["f32", "bf16x6"]
+for prec, joints, batch, full in [(p, *c) for p in PRECISIONS
+                                  for c in ((23, 1024, False), (23, 1024, True), (23, 4096, False), (18, 1024, False), (23, 256, False))]:
+    ops.set_precision(prec)
     data, tree = synthetic.make_batch(joints, 64, batch, seed=0, device="cuda")
     method = {"conditional": ["avg_speed_3d", "heading"], "grad_reversal": ["avg_speed_3d", "heading"], "adversarial_net": ["heading"]} if full else {}
     feats = ["avg_speed_3d", "heading"] if full else []
@@ -30,7 +33,7 @@ for joints, batch, full in ((23, 1024, False), (23, 1024, True), (23, 4096, Fals
         bl["total"].backward()
     torch.cuda.synchronize()
     table.update(ops.TUNED_LOG)
-    print(f"J={joints} B={batch} full={full}: {len(ops.TUNED_LOG)} geometries tuned so far", flush=True)
+    print(f"{prec} J={joints} B={batch} full={full}: {len(ops.TUNED_LOG)} geometries tuned so far", flush=True)
     del m
     torch.cuda.empty_cache()
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tuned_tiles.json")
