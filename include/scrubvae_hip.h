@@ -97,6 +97,8 @@ int svae_conv_dgrad_split(const svae_conv_desc* d, const float* dy, const void* 
                           int accumulate, int pieces, void* stream);
 int svae_conv_wgrad_split(const svae_conv_desc* d, const float* x, const float* dy, float* dw,
                           float* db, void* ws, size_t ws_bytes, int accumulate, int pieces, void* stream);
+/* introspection: tile, kernel variant and (halo variant) image rows of the split fwd (0) / dgrad (1) launch */
+int svae_conv_split_tile(const svae_conv_desc* d, int kind, int* bm, int* bn, int* variant, int* rmax);
 
 /* introspection: the (BM, BN) workgroup tile the dispatcher uses; kind 0 fwd, 1 dgrad, 2 wgrad */
 int svae_conv_tile(const svae_conv_desc* d, int kind, int* bm, int* bn);

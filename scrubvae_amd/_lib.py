@@ -65,6 +65,7 @@ SIGNATURES = {
     "svae_conv_fwd_split": (I, [DP, P, P, P, P, I, I, P]),
     "svae_conv_dgrad_split": (I, [DP, P, P, P, I, I, P]),
     "svae_conv_wgrad_split": (I, [DP, P, P, P, P, P, SZ, I, I, P]),
+    "svae_conv_split_tile": (I, [DP, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I)]),
     "svae_pack_input": (I, [P, P, C.POINTER(F), P, LL, I, I, P]),
     "svae_bn_chunks": (I, [LL]),
     "svae_bn_stats_partial": (I, [P, LL, I, I, P, P]),

@@ -84,6 +84,7 @@ struct SplitGatherArgs {
   GatherArgs g;               // g.W / g.ldW / g.w_tap_stride unused
   const unsigned short* Wp;   // weight pieces, pre-tiled [piece][tap][k/32][n][32] (zero padded in k)
   long long w_piece_stride;   // elements between piece planes
+  long long rowsA;            // rows of the gathered operand (batch * Lin): bound of the halo image
   int KB;                     // 32-deep k blocks per tap
 };
 
@@ -569,6 +570,255 @@ __global__ __launch_bounds__(64 * (4 + CWR * CWC)) void gather_gemm_bf16s_ws_ker
   }
 }
 
+// ----------------------------------------------------- gather GEMM with a halo image (fwd / dgrad)
+// The implicit-GEMM kernels above re-stage (load, split, write) the A tile for every tap although
+// consecutive taps read the SAME input rows shifted by one: a k-tap convolution converts every
+// activation k times.  Here one LDS image per 32-channel block holds all input rows a workgroup's
+// BM output rows touch over all taps (the tile's rows plus a halo: BM*stride + k - 1 rows); each
+// tap then reads that image with a row offset, and only the weight tile is staged per tap.  Rows
+// that a tap reaches across a sample boundary (conv padding) hold the neighbouring sample's data
+// and are zeroed in registers by the reader.  A-side global loads, split VALU and LDS writes drop
+// by ~k.  K loop order: channel block outer, tap inner.
+template <int BM, int BN, int P, int WR, int WC, int RMAX>
+__global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const SplitGatherArgs sa) {
+  const GatherArgs& g = sa.g;
+  constexpr int NTH = 64 * WR * WC;
+  constexpr int WM = BM / WR, MT = WM / 32, WN = BN / WC, NT = WN / 32;
+  static_assert(MT >= 1 && NT >= 1 && WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+  constexpr int RPP = NTH / 8;
+  constexpr int APASS = (RMAX + RPP - 1) / RPP;
+  constexpr int CH = 4;
+  constexpr int B_CHUNKS = P * BN * CH;
+  constexpr int BPASS = (B_CHUNKS + NTH - 1) / NTH;
+  constexpr bool B_EXACT = B_CHUNKS % NTH == 0;
+  constexpr int ROWB = SBK * 2;
+  constexpr int A_PIECE = RMAX * ROWB, B_PIECE = BN * ROWB;
+  constexpr int A_IMG = P * A_PIECE, B_STAGE = P * B_PIECE;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_IMG + 2 * B_STAGE];
+  __shared__ long long rowoff[BM];
+
+  const int tid = threadIdx.x;
+  int bx = blockIdx.x, phase = 0;
+  if (bx >= g.blocks_m[0]) { phase = 1; bx -= g.blocks_m[0]; }
+  const long long m0 = (long long)bx * BM;
+  const int n0 = blockIdx.y * BN;
+  const long long Mp = g.M[phase];
+  const int nj = g.nj[phase];
+  const int ntaps = g.ntaps[phase];
+  const int* __restrict__ tap_base = g.base[phase];
+  const int* __restrict__ tap_w = g.widx[phase];
+
+  // ---- extent of the image (uniform): anchor a(m) = b*Lin + j*sj, image row 0 = a(m0) + min base
+  int bmin = 1 << 30, bmax = -(1 << 30);
+  for (int t = 0; t < ntaps; ++t) {
+    const int b = tap_base[t];
+    bmin = b < bmin ? b : bmin;
+    bmax = b > bmax ? b : bmax;
+  }
+  const long long b0 = m0 / nj;
+  const long long amin = b0 * g.Lin + (long long)(m0 - b0 * nj) * g.sj;
+  const long long ml = (m0 + BM < Mp ? m0 + BM : Mp) - 1;
+  const long long bl = ml / nj;
+  const long long amax = bl * g.Lin + (long long)(ml - bl * nj) * g.sj;
+  const int R = (int)(amax - amin) + bmax - bmin + 1;  // <= RMAX (checked on the host)
+  const long long gbase = amin + bmin;
+
+  // ---- A image staging: 8 lanes per row, RPP rows per pass
+  const int akq = tid & 7;
+  long long a_goff[APASS];
+  bool a_row_ok[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int r = (tid >> 3) + RPP * i;
+    const long long grow = gbase + r;
+    a_row_ok[i] = r < R && grow >= 0 && grow < sa.rowsA;
+    a_goff[i] = (a_row_ok[i] ? grow : 0) * (long long)g.ldA;
+  }
+  if (tid < BM) {
+    const long long m = m0 + tid;
+    long long off = -1;
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      off = (b * g.Lout + (phase + g.n_phase * j)) * (long long)g.ldC;
+    }
+    rowoff[tid] = off;
+  }
+  int b_lds[BPASS];
+  long long b_goff[BPASS];
+  bool b_in[BPASS];
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    const int idx = tid + NTH * i;
+    const int piece = (idx / (BN * CH)) % P, rem = idx % (BN * CH);
+    const int row = rem / CH, ch = rem % CH;
+    b_in[i] = (B_EXACT || idx < B_CHUNKS) && n0 + row < g.N;
+    b_goff[i] = (long long)piece * sa.w_piece_stride + (long long)(b_in[i] ? n0 + row : 0) * SBK + ch * 8;
+    b_lds[i] = A_IMG + piece * B_PIECE + row * ROWB + ((ch ^ swz(row)) << 4);
+  }
+  const long long kb_stride = (long long)g.N * SBK;
+  const long long tap_stride = kb_stride * sa.KB;
+  const int ns = ntaps * sa.KB;
+
+  float4 ra[APASS];
+  bool ra_ok[APASS];
+  uint4 rb[BPASS];
+  auto load_a = [&](int kb) {
+    const int c0 = kb * SBK;
+    const bool kq_ok = c0 + akq * 4 < g.Kc;
+    const int cq = kq_ok ? c0 + akq * 4 : 0;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(g.A + a_goff[i] + cq);
+      ra_ok[i] = a_row_ok[i] && kq_ok;
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int r = (tid >> 3) + RPP * i;
+      uint2 pc[P];
+      split4<P>(ra_ok[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f), pc);
+      const int off = r * ROWB + (((akq >> 1) ^ swz(r)) << 4) + ((akq & 1) << 3);
+      if ((i + 1) * RPP <= RMAX || r < RMAX) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(smem + p * A_PIECE + off) = pc[p];
+      }
+    }
+  };
+  int nx_tap = 0, nx_kb = 0;
+  auto load_b = [&]() {
+    const int kbc = nx_kb < sa.KB ? nx_kb : sa.KB - 1;  // loads past the last stage re-read the last block
+    const unsigned short* wt = sa.Wp + (long long)tap_w[nx_tap] * tap_stride + (long long)kbc * kb_stride;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) rb[i] = *reinterpret_cast<const uint4*>(wt + b_goff[i]);
+    ++nx_tap;
+    const bool wrap = nx_tap >= ntaps;
+    nx_tap = wrap ? 0 : nx_tap;
+    nx_kb += wrap ? 1 : 0;
+  };
+  auto store_b = [&](int buf) {
+    unsigned char* st = smem + buf * B_STAGE;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const uint4 v = b_in[i] ? rb[i] : make_uint4(0u, 0u, 0u, 0u);
+      if constexpr (B_EXACT) {
+        *reinterpret_cast<uint4*>(st + b_lds[i]) = v;
+      } else {
+        if (tid + NTH * i < B_CHUNKS) *reinterpret_cast<uint4*>(st + b_lds[i]) = v;
+      }
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave / WC, wc = wave % WC;
+  const int lr = lane & 31, h = lane >> 5;
+  int ro[MT], jj[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const long long m = m0 + wr * WM + mt * 32 + lr;
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      ro[mt] = (int)(b * g.Lin + (long long)j * g.sj - amin) - bmin;
+      jj[mt] = j * g.sj;
+    } else {
+      ro[mt] = -bmin;
+      jj[mt] = -(1 << 28);
+    }
+  }
+  int b_addr[NT], b_sw[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int row = wc * WN + nt * 32 + lr;
+    b_addr[nt] = A_IMG + row * ROWB;
+    b_sw[nt] = swz(row);
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int buf, int tap) {
+    const int tb = tap_base[tap];
+    const unsigned char* bst = smem + buf * B_STAGE;
+    int arow[MT];
+    bool aval[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      arow[mt] = ro[mt] + tb;  // image row = a(m) - amin + (base - bmin)
+      aval[mt] = (unsigned)(jj[mt] + tb) < (unsigned)g.Lin;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 av[MT][P], bv[NT][P];
+      const int ch = ks * 2 + h;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const uint4 v = *reinterpret_cast<const uint4*>(smem + p * A_PIECE + arow[mt] * ROWB + ((ch ^ swz(arow[mt])) << 4));
+          av[mt][p] = aval[mt] ? v : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          bv[nt][p] = *reinterpret_cast<const uint4*>(bst + p * B_PIECE + b_addr[nt] + ((ch ^ b_sw[nt]) << 4));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_split<P>(av[mt], bv[nt], acc[mt][nt]);
+    }
+  };
+
+  if (ns > 0) {
+    load_a(0);
+    load_b();
+    store_b(0);
+    load_b();
+  }
+  int tap = 0, kb = 0;
+  for (int s = 0; s < ns; ++s) {
+    if (tap == 0) {  // new channel block: publish its image (the barrier also publishes weight stage s)
+      store_a();
+      __syncthreads();
+      load_a(kb + 1 < sa.KB ? kb + 1 : kb);
+    }
+    store_b((s & 1) ^ 1);
+    load_b();
+    compute(s & 1, tap);
+    __syncthreads();
+    if (++tap == ntaps) { tap = 0; ++kb; }
+  }
+  if (ns == 0) __syncthreads();  // rowoff
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + wc * WN + nt * 32 + lr;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long off = rowoff[row];
+        if (off >= 0) {
+          float* dst = g.C + off + col;
+          float v = acc[mt][nt][r] + bv;
+          if (g.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------- weight split
 // w[tap][c_in][c_out] fp32 -> bf16 piece planes, pre-tiled in the order the GEMM stages them:
 //   plane(n, k) at [piece][tap][k/32][n][k%32], k zero-padded to a multiple of 32.
@@ -838,10 +1088,39 @@ static void launch_split_dbg(const SplitGatherArgs& sa, dim3 grid, hipStream_t s
 #undef SVAE_DBG_CASE
 }
 
+// upper bound of the halo image rows over all BM-row tiles of both phases
+static int halo_rows(const GatherArgs& g, int bm) {
+  int worst = 0;
+  for (int p = 0; p < 2; ++p) {
+    if (g.M[p] <= 0 || g.ntaps[p] <= 0) continue;
+    int bmin = 1 << 30, bmax = -(1 << 30);
+    for (int t = 0; t < g.ntaps[p]; ++t) {
+      bmin = g.base[p][t] < bmin ? g.base[p][t] : bmin;
+      bmax = g.base[p][t] > bmax ? g.base[p][t] : bmax;
+    }
+    const int nj = g.nj[p];
+    int extra = g.Lin - nj * g.sj;  // additional anchor step at a sample boundary
+    if (extra < 0) extra = 0;
+    const int crossings = bm >= 2 ? (bm - 2) / nj + 1 : 0;
+    const int span = (bm - 1) * g.sj + crossings * extra + (bmax - bmin) + 1;
+    worst = span > worst ? span : worst;
+  }
+  return worst;
+}
+
+template <int BN>
+static int launch_halo(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
+  if (pieces != 3) { set_error("split gather: the halo kernel is built for 3 pieces only"); return SVAE_ERR_ARG; }
+  if (rows <= 160) hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 3, 4, 2, 160>), grid, dim3(512), 0, st, sa);
+  else if (rows <= 264) hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 3, 4, 2, 264>), grid, dim3(512), 0, st, sa);
+  else { set_error("split gather: halo image of %d rows does not fit", rows); return SVAE_ERR_ARG; }
+  return SVAE_OK;
+}
+
 // tile code V*1000000 + BM*1000 + BN.  V = 0: 4 waves, double-buffered LDS;  1: 4 waves, single LDS buffer;
 // 2: 8 waves (4x2), single buffer;  3: 8 waves, double-buffered (BM = 128 only);
 // 4: wave-specialised, 4 producer + 8 consumer waves, 2 tiles in flight;  5: same with 4 consumers;
-// 6 / 7: as 4 / 5 with 3 tiles in flight
+// 6 / 7: as 4 / 5 with 3 tiles in flight;  8: halo image kernel (BM = 128, 8 waves)
 static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, int pieces) {
   GatherArgs& g = sa.g;
   Tile t;
@@ -863,6 +1142,7 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
     else if (v == 6 && BM_ == 128) launch_split_ws<128, BN_, 4, 2, 3>(sa, grid, st, pieces);  \
     else if (v == 6 && BN_ == 128) launch_split_ws<64, 128, 2, 4, 3>(sa, grid, st, pieces);   \
     else if (v == 7) launch_split_ws<BM_, BN_, 2, 2, 3>(sa, grid, st, pieces);                \
+    else if (v == 8 && BM_ == 128) { if (int e = launch_halo<BN_>(sa, grid, st, pieces, halo_rows(g, 128))) return e; } \
     else if (v >= 10 && v < 26 && BM_ == 128 && BN_ == 128 && pieces == 3) launch_split_dbg(sa, grid, st, v - 10); \
     else { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_ARG; } \
   }
@@ -904,6 +1184,7 @@ extern "C" int svae_conv_fwd_split(const svae_conv_desc* d, const float* x, cons
   sa.Wp = (const unsigned short*)wsplit;  // Wf planes
   sa.w_piece_stride = plane_f(d);
   sa.KB = (d->c_in + 31) / 32;
+  sa.rowsA = (long long)d->batch * d->l_in;
   g.A = x; g.bias = bias; g.C = y;
   g.Kc = d->c_in; g.ldA = d->ld_in; g.ldC = d->ld_out;
   g.N = d->c_out;
@@ -924,10 +1205,27 @@ extern "C" int svae_conv_dgrad_split(const svae_conv_desc* d, const float* dy, c
   sa.Wp = (const unsigned short*)wsplit + 3 * plane_f(d);  // Wd planes
   sa.w_piece_stride = plane_d(d);
   sa.KB = (d->c_out + 31) / 32;
+  sa.rowsA = (long long)d->batch * d->l_out;
   g.A = dy; g.bias = nullptr; g.C = dx;
   g.Kc = d->c_out; g.ldA = d->ld_out; g.ldC = d->ld_in;
   g.N = d->c_in;
   g.accumulate = accumulate;
   build_plan(g, d, /*strided=*/d->transposed != 0, d->l_in, d->l_out);
   return launch_split_gather(sa, (hipStream_t)stream, d->tile[1], pieces);
+}
+
+/* kernel the split dispatcher uses for kind 0 (fwd) / 1 (dgrad): workgroup tile, variant and -- for the halo
+ * variant -- the image rows it is instantiated with (0 otherwise) */
+extern "C" int svae_conv_split_tile(const svae_conv_desc* d, int kind, int* bm, int* bn, int* variant, int* rmax) {
+  if (int e = validate(d)) return e;
+  SVAE_REQUIRE(bm && bn && variant && rmax && (kind == 0 || kind == 1), SVAE_ERR_ARG, "conv_split_tile: bad args");
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  if (kind == 0) { g.N = d->c_out; build_plan(g, d, !d->transposed, d->l_out, d->l_in); }
+  else { g.N = d->c_in; build_plan(g, d, d->transposed != 0, d->l_in, d->l_out); }
+  Tile t;
+  if (!decode_tile(d->tile[kind], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
+  *bm = t.bm; *bn = t.bn; *variant = t.dma; *rmax = 0;
+  if (t.dma == 8) { const int r = halo_rows(g, 128); *rmax = r <= 160 ? 160 : 264; }
+  return SVAE_OK;
 }

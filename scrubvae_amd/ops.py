@@ -87,12 +87,12 @@ _KIND_ID = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 # is as accurate as f32.  Read when a Conv is constructed; convs below SPLIT_MIN_FLOPS stay f32.
 PRECISION = os.environ.get("SVAE_PRECISION", "f32")
 _PIECES = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1}
-SPLIT_MIN_FLOPS = float(os.environ.get("SVAE_SPLIT_MIN_FLOPS", 2e8))
+SPLIT_MIN_FLOPS = float(os.environ.get("SVAE_SPLIT_MIN_FLOPS", 1e9))
 # VBBBNNN: V = 0: 4 waves, double-buffered LDS; 1: 4 waves, one LDS buffer; 2 / 3: 8 waves (BM = 128), one / two buffers
 # 4: wave-specialised (4 producer + 8 consumer waves); 5: wave-specialised 4 + 4
 _SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2128064, 3128128, 3128064)
                        + (4128128, 4128064, 4064128) + tuple(5000000 + c for c in _TILES)
-                       + (6128128, 6128064, 6064128) + tuple(7000000 + c for c in _TILES))
+                       + (6128128, 6128064, 6064128) + tuple(7000000 + c for c in _TILES) + (8128128, 8128064))
 _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2, 1"}
 _SPLIT_WGRAD_CODES = _TILES + tuple(1000000 + c for c in _TILES)  # 1BBBNNN: single LDS buffer
 MIX_F32 = True  # a bf16x6 conv may keep the fp32 MFMA kernel for a pass where that is faster (same accuracy)
@@ -219,12 +219,17 @@ class Conv:
             if kp and kind == "wgrad":
                 names[kind] = f"wgrad_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}, {1 if self.desc.tile[2] >= 1000000 else 2}>"
             elif kp:
-                v = bm.value // 1000 if self.desc.tile[_KIND_ID[kind]] > 0 else 1
-                if v >= 4:
-                    cw = "2, 2" if v in (5, 7) else ("4, 2" if bm.value % 1000 == 128 else "2, 4")
-                    names[kind] = f"gather_gemm_bf16s_ws_kernel<{bm.value % 1000}, {bn.value}, {kp}, {cw}, {2 if v < 6 else 3}>"
+                v, rm = C.c_int(), C.c_int()
+                check(_lib.lib().svae_conv_split_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn), C.byref(v),
+                                                      C.byref(rm)), "conv_split_tile")
+                v = v.value
+                if v == 8:
+                    names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {kp}, 4, 2, {rm.value}>"
+                elif v >= 4:
+                    cw = "2, 2" if v in (5, 7) else ("4, 2" if bm.value == 128 else "2, 4")
+                    names[kind] = f"gather_gemm_bf16s_ws_kernel<{bm.value}, {bn.value}, {kp}, {cw}, {2 if v < 6 else 3}, 0>"
                 else:
-                    names[kind] = f"gather_gemm_bf16s_kernel<{bm.value % 1000}, {bn.value}, {kp}, {_SPLIT_VARIANT[v]}>"
+                    names[kind] = f"gather_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}, {_SPLIT_VARIANT[v]}>"
             elif kind == "wgrad":
                 names[kind] = (f"wgrad_fused_kernel<{-bm.value}, {'false' if self.desc.transposed else 'true'}>" if bm.value < 0
                                else f"wgrad_gemm_kernel<{bm.value}, {bn.value}>")

@@ -386,7 +386,7 @@ def _split_cases():
     for case in CONV_CASES:
         for code in (128128, 64128, 128064, 64064, 1128128, 1064128, 1128064, 1064064, 2128128, 2128064, 3128128, 3128064,
                      4128128, 4128064, 4064128, 5128128, 5128064, 5064128, 5064064,
-                     6128128, 6128064, 6064128, 7128128, 7128064, 7064128, 7064064, 0):
+                     6128128, 6128064, 6064128, 7128128, 7128064, 7064128, 7064064, 8128128, 8128064, 0):
             out.append((case, code, 3))
         out.append((case, 64064, 2))
         out.append((case, 2128064, 2))

@@ -6,7 +6,7 @@ import csv, glob, json, sys, collections
 
 def load(d):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(f"{d}/*/*counter_collection.csv"):
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
