@@ -91,6 +91,14 @@ int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const float* dy, fl
  * workgroup / LDS buffering, see gemm_bf16s.hip). */
 size_t svae_conv_split_bytes(const svae_conv_desc* d);
 int svae_conv_split_weights(const svae_conv_desc* d, const float* w, void* wsplit, void* stream);
+/* the same for up to SVAE_MAX_SPLIT_TASKS convolutions in one launch (all layers of a model, once per step) */
+#define SVAE_MAX_SPLIT_TASKS 48
+typedef struct {
+  const float* w;   /* fp32 master weights [kernel][c_in][c_out] (padded channel counts) */
+  void* wsplit;     /* svae_conv_split_bytes() bytes */
+  int kernel, c_in, c_out;
+} svae_split_task;
+int svae_conv_split_weights_batched(const svae_split_task* tasks, int n, void* stream);
 int svae_conv_fwd_split(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias,
                         float* y, int accumulate, int pieces, void* stream);
 int svae_conv_dgrad_split(const svae_conv_desc* d, const float* dy, const void* wsplit, float* dx,

@@ -27,6 +27,13 @@ class ColsumTask(C.Structure):
 MAX_COLSUM_TASKS = 48
 
 
+class SplitTask(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wsplit", C.c_void_p), ("kernel", C.c_int), ("c_in", C.c_int), ("c_out", C.c_int)]
+
+
+MAX_SPLIT_TASKS = 48
+
+
 class Tree(C.Structure):
     _fields_ = [("n_joints", C.c_int), ("n_chains", C.c_int),
                 ("chain_len", C.c_int * MAX_CHAINS),
@@ -62,6 +69,7 @@ SIGNATURES = {
     "svae_conv_tile": (I, [DP, I, C.POINTER(I), C.POINTER(I)]),
     "svae_conv_split_bytes": (SZ, [DP]),
     "svae_conv_split_weights": (I, [DP, P, P, P]),
+    "svae_conv_split_weights_batched": (I, [C.POINTER(SplitTask), I, P]),
     "svae_conv_fwd_split": (I, [DP, P, P, P, P, I, I, P]),
     "svae_conv_dgrad_split": (I, [DP, P, P, P, I, I, P]),
     "svae_conv_wgrad_split": (I, [DP, P, P, P, P, P, SZ, I, I, P]),

@@ -824,13 +824,11 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
 //   plane(n, k) at [piece][tap][k/32][n][k%32], k zero-padded to a multiple of 32.
 //   Wf: n = c_out, k = c_in (forward)      Wd: n = c_in, k = c_out (data gradient)
 // One workgroup converts a 32 (n) x 32 (k) block; Wf goes through an LDS transpose.
-__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                                            int T, int Cin, int Cout, int to_wd, long long piece_stride) {
-  __shared__ float tile[32][33];
+__device__ __forceinline__ void split_block(const float* __restrict__ w, unsigned short* __restrict__ out, int T, int Cin, int Cout,
+                                            int to_wd, long long piece_stride, int nb, int kb, int t, float (*tile)[33]) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int N = to_wd ? Cin : Cout, K = to_wd ? Cout : Cin;
   const int KB = (K + 31) / 32;
-  const int nb = blockIdx.x, kb = blockIdx.y, t = blockIdx.z;
   const int n0 = nb * 32, k0 = kb * 32;
   float v[4];
   if (to_wd) {  // source rows are n (= c_in), contiguous in k (= c_out)
@@ -862,6 +860,40 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
       x = residual(x);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                            int T, int Cin, int Cout, int to_wd, long long piece_stride) {
+  __shared__ float tile[32][33];
+  split_block(w, out, T, Cin, Cout, to_wd, piece_stride, blockIdx.x, blockIdx.y, blockIdx.z, tile);
+}
+
+// all convolutions of a model in ONE launch: block -> (task, direction, tap, k block, n block)
+struct SplitTasks {
+  const float* w[SVAE_MAX_SPLIT_TASKS];
+  unsigned short* out[SVAE_MAX_SPLIT_TASKS];
+  int T[SVAE_MAX_SPLIT_TASKS], Cin[SVAE_MAX_SPLIT_TASKS], Cout[SVAE_MAX_SPLIT_TASKS];
+  int first[SVAE_MAX_SPLIT_TASKS + 1];  // first block of each task
+  int n;
+};
+
+__global__ __launch_bounds__(256) void split_weights_batched_kernel(const SplitTasks ts) {
+  __shared__ float tile[32][33];
+  int k = 0;
+  while (k + 1 < ts.n && (int)blockIdx.x >= ts.first[k + 1]) ++k;
+  const int T = ts.T[k], Cin = ts.Cin[k], Cout = ts.Cout[k];
+  const int bi = (Cin + 31) / 32, bo = (Cout + 31) / 32;
+  int b = blockIdx.x - ts.first[k];
+  const int per_dir = T * bi * bo;
+  const int to_wd = b >= per_dir;
+  b -= to_wd ? per_dir : 0;
+  const int t = b / (bi * bo);
+  b -= t * bi * bo;
+  // Wf: n = c_out (bo blocks), k = c_in (bi blocks);  Wd: n = c_in, k = c_out
+  const int nblocks = to_wd ? bi : bo;
+  const int kb = b / nblocks, nb = b - kb * nblocks;
+  const long long pf = (long long)T * bi * 32 * Cout, pd = (long long)T * bo * 32 * Cin;
+  split_block(ts.w[k], ts.out[k] + (to_wd ? 3 * pf : 0), T, Cin, Cout, to_wd, to_wd ? pd : pf, nb, kb, t, tile);
 }
 
 // ------------------------------------------------------------------------------ weight grad
@@ -1228,4 +1260,25 @@ extern "C" int svae_conv_split_tile(const svae_conv_desc* d, int kind, int* bm, 
   *bm = t.bm; *bn = t.bn; *variant = t.dma; *rmax = 0;
   if (t.dma == 8) { const int r = halo_rows(g, 128); *rmax = r <= 160 ? 160 : 264; }
   return SVAE_OK;
+}
+
+extern "C" int svae_conv_split_weights_batched(const svae_split_task* tasks, int n, void* stream) {
+  SVAE_REQUIRE(tasks && n > 0 && n <= SVAE_MAX_SPLIT_TASKS, SVAE_ERR_ARG, "split_weights_batched: 1..%d tasks", SVAE_MAX_SPLIT_TASKS);
+  SplitTasks ts;
+  memset(&ts, 0, sizeof(ts));
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const svae_split_task& k = tasks[i];
+    SVAE_REQUIRE(k.w && k.wsplit && aligned16(k.w) && aligned16(k.wsplit) && k.kernel >= 1 && k.c_in > 0 && k.c_out > 0 &&
+                     k.c_in % 16 == 0 && k.c_out % 16 == 0,
+                 SVAE_ERR_ARG, "split_weights_batched: bad task %d", i);
+    ts.w[i] = k.w; ts.out[i] = (unsigned short*)k.wsplit;
+    ts.T[i] = k.kernel; ts.Cin[i] = k.c_in; ts.Cout[i] = k.c_out;
+    ts.first[i] = total;
+    total += 2 * k.kernel * ((k.c_in + 31) / 32) * ((k.c_out + 31) / 32);
+  }
+  ts.first[n] = total;
+  ts.n = n;
+  hipLaunchKernelGGL(split_weights_batched_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, ts);
+  return check_launch("split_weights_batched");
 }

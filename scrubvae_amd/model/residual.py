@@ -187,6 +187,7 @@ class ResVAE(nn.Module):
         self._sides, self._side_dirty, self._events, self._event_i = [], set(), [], 0
         self._ws = {}
         self._convs = {}
+        self._split_users = {}  # conv key -> (Conv, parameter module) of every conv on the split-bf16 path
         self._runners = {}
         self._pending = None
         self._db_batch = ops.ColsumBatch()
@@ -279,6 +280,8 @@ class ResVAE(nn.Module):
         if c is None:
             c = ops.Conv(batch, l_in, p.c_in, p.c_out, p.kernel, p.stride, p.padding, p.dilation, p.transposed, ld_in, ld_out)
             self._convs[key] = c
+            if c.pieces:
+                self._split_users[key] = (c, p)
         return c
 
     def _lin(self, name, p: LinearP, batch, ld_in=None, ld_out=None):
@@ -288,7 +291,17 @@ class ResVAE(nn.Module):
             c = ops.Conv(batch, 1, p.in_lib, p.out_lib, 1, ld_in=ld_in, ld_out=ld_out)
             c.flops = 2.0 * batch * p.in_f * p.out_f  # algorithmic: unpadded features
             self._convs[key] = c
+            if c.pieces:
+                self._split_users[key] = (c, p)
         return c
+
+    def _new_pass(self):
+        """Start of forward / encode / decode: the master weights may have changed since the last pass, so
+        the split-bf16 weight copies of every conv seen so far are refreshed in one launch (convs met for
+        the first time in this pass split lazily at their first use)."""
+        ops.bump_weight_epoch()
+        if self._split_users:
+            ops.split_weights_batched([(c, p.weight) for c, p in self._split_users.values()])
 
     def _wgrad_ws(self, conv):
         n = conv.wgrad_workspace_bytes() // 4 + 16
@@ -574,7 +587,7 @@ class ResVAE(nn.Module):
     # ------------------------------------------------------------------ reference API
     def encode(self, data):
         """ResVAE.encode (residual.py:438-459): returns {"mu": [B,z], "L": [B,z,z]}."""
-        ops.bump_weight_epoch()
+        self._new_pass()
         B, flat, h = self._encode_trunk(data)
         mu, sigma, zc, klp = self._heads(B, h, None)
         self._state = dict(B=B, flat=flat, h=h, eps=None)
@@ -582,7 +595,7 @@ class ResVAE(nn.Module):
 
     def decode(self, z, data):
         """ResVAE.decode (residual.py:461-491)."""
-        ops.bump_weight_epoch()
+        self._new_pass()
         B = z.shape[0]
         zcp = pad16(self.z_dim + self.conditional_dim)
         zc = self._buf("dec.zc", (B, zcp), zero=True)
@@ -606,7 +619,7 @@ class ResVAE(nn.Module):
     def forward(self, data):
         """VAE.forward (residual.py:318-362).  Returns data_o with mu, L, z, x6d, root, var,
         disentangle[method][feature]."""
-        ops.bump_weight_epoch()  # split-bf16 weight copies (if any) are refreshed on first use in this pass
+        self._new_pass()
         B, flat, h = self._encode_trunk(data)
         eps = None
         if self.training:

@@ -106,6 +106,25 @@ def set_precision(name):
     PRECISION = name
 
 
+def split_weights_batched(users):
+    """users: iterable of (Conv, weight).  Splits the weights of every conv that runs a split-bf16 forward or
+    data-gradient in one launch per MAX_SPLIT_TASKS and marks their copies current for this weight epoch."""
+    todo = [(cv, w) for cv, w in users
+            if cv.pieces and (cv._kind_pieces("fwd") or cv._kind_pieces("dgrad"))
+            and (cv._split_epoch != WEIGHT_EPOCH or cv._split_src != w.data_ptr())]
+    for i in range(0, len(todo), _lib.MAX_SPLIT_TASKS):
+        chunk = todo[i: i + _lib.MAX_SPLIT_TASKS]
+        arr = (_lib.SplitTask * len(chunk))()
+        for t, (cv, w) in zip(arr, chunk):
+            if cv._wsplit is None:
+                n = int(_lib.lib().svae_conv_split_bytes(C.byref(cv.desc)))
+                cv._wsplit = torch.empty(n + 64, dtype=torch.uint8, device=w.device)
+            t.w, t.wsplit, t.kernel, t.c_in, t.c_out = w.data_ptr(), cv._wsplit.data_ptr(), cv.kernel, cv.c_in_p, cv.c_out_p
+        check(_lib.lib().svae_conv_split_weights_batched(arr, len(chunk), _stream()), "conv_split_weights_batched")
+        for cv, w in chunk:
+            cv._split_epoch, cv._split_src = WEIGHT_EPOCH, w.data_ptr()
+
+
 def bump_weight_epoch():
     """Invalidate the split-bf16 weight copies: the next use of each Conv re-splits its weights."""
     global WEIGHT_EPOCH

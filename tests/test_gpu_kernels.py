@@ -469,3 +469,25 @@ def test_split_weight_copies_follow_the_epoch(ops):
     cv.fwd(x, w, None, y2)
     assert torch.equal(y0, y1)
     assert relerr(y2, 2 * y0) < 1e-6
+
+
+def test_split_weights_batched_matches_single(ops):
+    """One batched launch over several convs writes the same piece planes as the per-conv kernel."""
+    g = torch.Generator().manual_seed(5)
+    specs = [(2, 8, 48, 32, 5, 1, 2, False), (2, 8, 64, 144, 6, 1, 2, False), (3, 4, 32, 16, 5, 2, 2, True), (4, 1, 80, 32, 1, 1, 0, False)]
+    convs, ws = [], []
+    for B, L, cin, cout, k, s, p, tr in specs:
+        cv = ops.Conv(B, L, cin, cout, k, s, p, 1, tr, pieces=3)
+        w = torch.randn(*cv.weight_shape, generator=g).cuda()
+        convs.append(cv); ws.append(w)
+    ops.bump_weight_epoch()
+    single = [cv.split_weights(w).clone() for cv, w in zip(convs, ws)]
+    for cv in convs:
+        cv._wsplit.zero_()
+    ops.bump_weight_epoch()
+    ops.split_weights_batched(list(zip(convs, ws)))
+    torch.cuda.synchronize()
+    for cv, ref in zip(convs, single):
+        assert cv._split_epoch == ops.WEIGHT_EPOCH
+        n = ref.numel() - 64
+        assert torch.equal(cv._wsplit[:n], ref[:n])
