@@ -591,3 +591,47 @@ def skeleton_tree(J):
         t[0].append(18); t[2].append(19); t[3].append(20); t[4].append(21); t[5].append(22)
         return t
     return [list(range(J))]
+
+
+# ------------------------------------------------------------------ eval forward
+GEN_SPD_STD = (0.4038, 0.3586, 0.4169)   # constants of eval/eval.py:43-57,106-113
+GEN_SPD_MEAN = (0.4993, 0.7112, 0.6663)
+GEN_SPD_MIN = (-1.2323, -1.9734, -1.5858)
+GEN_SPD_MAX = (4.6167, 4.6437, 4.2551)
+GEN_PARTS = ([0, 1, 2, 3, 4, 5], [1, 6, 7, 8, 9, 10, 11], [5, 12, 13, 14, 15, 16, 17])
+
+
+def generative_restrictiveness(sd, cfg, z, data, key, rand):
+    """eval/eval.py:22-120: re-decode z with a re-drawn conditional variable `key` and measure the
+    variable on the generated pose.  rand = the uniform [B] (heading, torch.rand at :29) or normal
+    [B,1] (avg_speed_3d, torch.randn at :46) draw.  Returns (pred, target, data_mod) where target is the
+    REPLACED data[key] (the reference mutates `data` and returns the new value, :120)."""
+    import math
+    data = dict(data)
+    dt = z.dtype
+    B, W, J = data["x6d"].shape[0], data["x6d"].shape[1], data["x6d"].shape[-2]
+    if key == "heading":
+        yaw = (rand.to(dt) * 2 - 1)[:, None] * math.pi
+        data["heading"] = torch.cat([torch.sin(yaw), torch.cos(yaw)], dim=-1)
+    elif key == "avg_speed_3d":
+        jitter = rand.to(dt) * torch.tensor(GEN_SPD_STD, dtype=dt) * 1.5 + 0.5
+        data["avg_speed_3d"] = torch.clamp(data[key] + jitter, min=torch.tensor(GEN_SPD_MIN, dtype=dt),
+                                           max=torch.tensor(GEN_SPD_MAX, dtype=dt))
+    out = decode(sd, cfg, z, data, False)
+    pose = fwd_kin(out["x6d"].reshape(-1, J, 6), cfg.kinematic_tree, data["offsets"].reshape(-1, J, 3).to(dt),
+                   out["root"].reshape(-1, 3), eps=1e-8).reshape(B, W, J, 3)
+    if key == "heading":
+        fwd = pose[:, W // 2, 1, :] - pose[:, W // 2, 0, :]
+        fwd = fwd / torch.linalg.norm(fwd, dim=-1)[..., None]
+        yaw = -torch.arctan2(fwd[:, 1], fwd[:, 0])[:, None]
+        pred = torch.cat([torch.sin(yaw), torch.cos(yaw)], dim=-1)
+    else:
+        root_spd = torch.sqrt((torch.diff(pose[:, :, 0, :], n=1, dim=-2) ** 2).sum(dim=-1)).mean(dim=-1)
+        dxyz = []
+        for part in GEN_PARTS:
+            rel = pose - pose[:, W // 2, part[0], :][:, None, None, :]
+            d = (torch.diff(rel[..., part[1:], :], n=1, dim=-3) ** 2).sum(dim=-1)
+            dxyz.append(torch.sqrt(d).mean(dim=(-1, -2)))
+        pred = torch.stack([root_spd, dxyz[0], (dxyz[1] + dxyz[2]) / 2], dim=-1)
+        pred = (pred - torch.tensor(GEN_SPD_MEAN, dtype=dt)) / torch.tensor(GEN_SPD_STD, dtype=dt)
+    return pred, data[key], data

@@ -195,6 +195,42 @@ def train_test_epoch(config, model, loader, device, epoch, optimizer=None, sched
     return epoch_metrics
 
 
+def test_epoch(config, model, loader, device="cuda", epoch=0):
+    """trainer.py:215-303: eval-mode pass over `loader` -> (epoch_metrics incl. r2_gen_restrict_<key>, mu [N,z] on
+    the CPU).  The `mcmi` estimator refresh (trainer.py:230-256) belongs to the streaming-scrubber row (SURVEY 8a
+    A2 / 8f N4) and raises here rather than silently skipping."""
+    from sklearn.metrics import r2_score
+
+    from ..eval import generative_restrictiveness
+    print("Running test epoch")
+    if "mcmi" in config["loss"].keys():
+        raise NotImplementedError("test_epoch: the mcmi mutual-information estimator is not on the HIP path (SURVEY 8f N4)")
+    model.eval()
+    with torch.no_grad():
+        z = []
+        epoch_metrics = {k: 0 for k in ["total"] + list(config["loss"].keys())}
+        gen_res = {k1: {k2: [] for k2 in ["pred", "target"]} for k1 in model.disentangle_keys if k1 != "ids"}
+        n_batches = 0
+        for batch_idx, data in enumerate(loader):
+            data = {k: v.to(device) for k, v in data.items()}
+            data_o = predict_batch(model, data, model.disentangle_keys)
+            z += [data_o["mu"].clone().detach()]
+            batch_metrics = get_batch_loss(model, data, data_o, config["loss"], config["disentangle"])
+            for key in gen_res.keys():
+                key_pred, key_target = generative_restrictiveness(model, data_o["mu"], data, key, loader.dataset.kinematic_tree)
+                gen_res[key]["pred"] += [key_pred.detach().cpu()]
+                gen_res[key]["target"] += [key_target.detach().cpu()]
+            epoch_metrics = {k: v + batch_metrics[k].detach() for k, v in epoch_metrics.items()}
+            n_batches += 1
+    for k, v in epoch_metrics.items():
+        epoch_metrics[k] = (v.item() if torch.is_tensor(v) else float(v)) / max(n_batches, 1)
+        print("====> Epoch: {} Average {} loss: {:.4f}".format(epoch, k, epoch_metrics[k]))
+    for key in gen_res.keys():
+        epoch_metrics["r2_gen_restrict_{}".format(key)] = r2_score(torch.cat(gen_res[key]["target"], dim=0),
+                                                                    torch.cat(gen_res[key]["pred"], dim=0))
+    return epoch_metrics, torch.cat(z, dim=0).cpu()
+
+
 def train_epoch(config, model, loader, optimizer, scheduler, device="cuda", epoch=0):
     return train_test_epoch(config, model, loader, device, epoch, optimizer, scheduler, mode="train")
 

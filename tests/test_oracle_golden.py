@@ -132,3 +132,28 @@ def test_shape_math_quirks():
     assert O.find_latent_dim(64, 5, 4) == 4 and O.find_out_dim(4, 5, 4) == 49
     assert O.final_kernel(O.OracleConfig()) == 22
     assert O.find_latent_dim(256, 5, 6) == 4
+
+
+EVAL_CFG = O.OracleConfig(diag=True, method={"conditional": ["avg_speed_3d", "heading"]}, features=["avg_speed_3d", "heading"],
+                          discrete_classes={"ids": torch.arange(4)}, **TINY)
+
+
+def load_eval_fixture(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "eval_full_tiny.npz"))
+    sd = {k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd/")}
+    data = {k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("in/")}
+    return fx, sd, data
+
+
+def test_oracle_eval_forward_matches_reference(golden_dir):
+    """eval-mode encode + eval/eval.py generative_restrictiveness of the real reference
+    (tests/golden/make_fixtures.py --eval-only) vs the oracle restatement, with the re-draw injected."""
+    fx, sd, data = load_eval_fixture(golden_dir)
+    enc = O.encode(sd, EVAL_CFG, data, False)
+    assert rel(enc["mu"], fx["enc/mu"]) < 2e-5
+    assert rel(enc["L"], fx["enc/L"]) < 2e-5
+    for key in ("heading", "avg_speed_3d"):
+        pred, target, _ = O.generative_restrictiveness(sd, EVAL_CFG, torch.from_numpy(fx["enc/mu"]), data, key,
+                                                       torch.from_numpy(fx[f"gen/{key}/draw"]))
+        assert rel(target, fx[f"gen/{key}/target"]) < 1e-6, key
+        assert rel(pred, fx[f"gen/{key}/pred"]) < 2e-5, key
