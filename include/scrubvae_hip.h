@@ -261,6 +261,22 @@ size_t svae_colsum_batched_workspace(const svae_colsum_task* tasks, int n);
 int svae_colsum_batched(const svae_colsum_task* tasks, int n, void* ws, size_t ws_bytes, int accumulate,
                         void* stream);
 
+/* --------------------------------------------------------- preprocessing --- */
+/* inv_kin (dataset.py:11-46, forward_indices=[1,0]) + root centring / "midfwd" re-orientation (dataset.py:385-404)
+ * + quaternion_to_cont6d (quaternion.py:291-334) + get_segment_len (dataset.py:279-296) + heading of the window's
+ * middle frame (dataset.py:234-241,258-265), one thread per frame.
+ *   pose [frames][J][3] (frames = windows*window, windowed order), unit_offset = HOST pointer [J][3]
+ *   -> x6d [frames][J][6]; offsets [frames][J][3], root [frames][3], heading [frames/window][2] (each may be NULL).
+ * truncate_len != 0 reproduces the reference when OFFSET is an integer array (segment lengths truncated toward
+ * zero on assignment, dataset.py:289-294).  Frame 0 gets the identity root quaternion (dataset.py:31). */
+int svae_inv_kin(const float* pose, const float* unit_offset_host, const svae_tree* tree, int window, int midfwd,
+                 int centre_root, int truncate_len, float* x6d, float* offsets, float* root, float* heading,
+                 long long frames, void* stream);
+/* get_speed_parts (dataset.py:133-163) + limbs averaged (:373-375): pose [windows][W][J][3] -> out [windows][3].
+ * parts_host: the part joint lists concatenated (HOST), part_len_host[n_parts] their lengths (HOST). */
+int svae_speed_parts(const float* pose, const int* parts_host, const int* part_len_host, int n_parts, int W, int J,
+                     float* out, long long windows, void* stream);
+
 /* ------------------------------------------------------------------------- optimizer --- */
 /* O1: torch.optim.AdamW / Adam step over one flat fp32 buffer (trainer.py:60-65,165).
  * step_t = 1-based step count; decoupled != 0 => AdamW. grad_scale multiplies g first

@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["capi.hip", "gemm_f32.hip", "gemm_bf16s.hip", "elementwise.hip", "pose_tail.hip", "latent.hip"]
+SOURCES = ["capi.hip", "gemm_f32.hip", "gemm_bf16s.hip", "elementwise.hip", "pose_tail.hip", "latent.hip", "preprocess.hip"]
 OUT = os.path.join(CSRC, "libscrubvae_hip.so")
 
 
