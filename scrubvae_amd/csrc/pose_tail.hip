@@ -127,24 +127,32 @@ __device__ __forceinline__ void c6_to_mat_bwd(const float* a, const M3& dM, floa
   da[2] = gx[2] * ix - a[2] * kx;
 }
 
-__global__ __launch_bounds__(64) void pose_tail_kernel(const TailArgs g) {
+// One workgroup per 64 consecutive frames, one WAVE PER KINEMATIC CHAIN (lane = frame): the chains only couple
+// through (a) the position of the joint a chain starts from and (b) the gradient of the shared root rotation,
+// so the expensive per-chain work (rotation products forward, chain-product backward) runs in parallel waves
+// over the same LDS tile; the cheap coupling steps run on wave 0 between barriers.  A single wave per workgroup
+// (the previous version) left the CU with one resident wave because the tile takes ~90 KB of LDS.
+__global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const TailArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63;
   const int J = g.J, J3 = 3 * J, C6 = 6 * J;
   const int ldt = g.ldt, ldo = g.ldo;
   float* tile = smem;                // [64][ldt] tanh outputs, later gradients
   float* offs = tile + 64 * ldt;     // [64][ldo]
   float* tg = offs + 64 * ldo;       // [64][ldo] targets -> position grads
-  float* pose = tg + 64 * ldo;       // [64][ldo]
+  float* pose = tg + 64 * ldo;       // [64][ldo] positions (relative to the chain start until phase 2)
+  float* dm0 = pose + 64 * ldo;      // [n_chains][64][9] per-chain gradient of the root rotation
   const long long r0 = (long long)blockIdx.x * 64;
   const int nrows = (int)((g.rows - r0) < 64 ? (g.rows - r0) : 64);
+  const int n_chains = g.tree.n_chains;
 
-  // ---- stage: y tile (tanh applied), offsets, targets
+  // ---- phase 0 (all threads): stage y tile (tanh applied), offsets, targets
   {
     const int f4_per_row = g.ld / 4;
     const int total = nrows * f4_per_row;
     const float* src = g.y + r0 * g.ld;
-    for (int e = lane; e < total; e += 64) {
+    for (int e = tid; e < total; e += nth) {
       const int rr = e / f4_per_row, c = (e - rr * f4_per_row) * 4;
       const float4 v = *reinterpret_cast<const float4*>(src + (long long)e * 4);
       float* d = tile + rr * ldt + c;
@@ -154,176 +162,204 @@ __global__ __launch_bounds__(64) void pose_tail_kernel(const TailArgs g) {
     const int tot3 = nrows * J3;
     const float* so = g.offsets + r0 * J3;
     const float* stg = g.target + r0 * J3;
-    for (int e = lane; e < tot3; e += 64) {
+    for (int e = tid; e < tot3; e += nth) {
       const int rr = e / J3, c = e - rr * J3;
       offs[rr * ldo + c] = so[e];
       tg[rr * ldo + c] = stg[e];
     }
   }
   __syncthreads();
-  // ---- write x6d_hat / root_hat (coalesced)
+  // ---- write x6d_hat / root_hat (coalesced, all threads)
   {
     const int tot6 = nrows * C6;
     float* dst = g.x6d_hat + r0 * C6;
-    for (int e = lane; e < tot6; e += 64) {
+    for (int e = tid; e < tot6; e += nth) {
       const int rr = e / C6, c = e - rr * C6;
       dst[e] = tile[rr * ldt + c];
     }
     if (g.has_arena) {
       float* dr = g.root_hat + r0 * 3;
-      for (int e = lane; e < nrows * 3; e += 64) {
+      for (int e = tid; e < nrows * 3; e += nth) {
         const int rr = e / 3, k = e - rr * 3;
         dr[e] = 0.5f * (tile[rr * ldt + C6 + k] + 1.f) * (g.a1[k] - g.a0[k]) + g.a0[k];
       }
     }
   }
 
-  float jpe = 0.f, rl = 0.f;
   const bool active = lane < nrows;
   float* my = tile + lane * ldt;
   float* myo = offs + lane * ldo;
   float* myt = tg + lane * ldo;
   float* myp = pose + lane * ldo;
   const bool do_bwd = g.dy != nullptr;
+  const bool chain_wave = wave < n_chains && g.tree.chain_len[wave < n_chains ? wave : 0] >= 2;
+  const int ch = wave < n_chains ? wave : 0;
+  const int len = g.tree.chain_len[ch];
 
+  // ---- phase 1 (wave = chain): rotations along the chain, positions relative to the chain's first joint
+  float a6[6];
+  M3 M0;
   if (active) {
-    for (int c = 0; c < J3; ++c) myp[c] = 0.f;
-    float a6[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) a6[k] = my[k];
-    const M3 M0 = c6_to_mat(a6);
-    // ---- forward kinematics
-    for (int ch = 0; ch < g.tree.n_chains; ++ch) {
-      const int len = g.tree.chain_len[ch];
-      M3 R = M0;
-      for (int i = 1; i < len; ++i) {
-        const int j = g.tree.chain[ch][i], par = g.tree.chain[ch][i - 1];
+    M0 = c6_to_mat(a6);
+  }
+  if (active && chain_wave) {
+    M3 R = M0;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int i = 1; i < len; ++i) {
+      const int j = g.tree.chain[ch][i];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) a6[k] = my[6 * j + k];
-        R = mul(R, c6_to_mat(a6));
-        const float o0 = myo[3 * j], o1 = myo[3 * j + 1], o2 = myo[3 * j + 2];
+      for (int k = 0; k < 6; ++k) a6[k] = my[6 * j + k];
+      R = mul(R, c6_to_mat(a6));
+      const float o0 = myo[3 * j], o1 = myo[3 * j + 1], o2 = myo[3 * j + 2];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) myp[3 * j + r] = R.m[r * 3] * o0 + R.m[r * 3 + 1] * o1 + R.m[r * 3 + 2] * o2 + myp[3 * par + r];
+      for (int r = 0; r < 3; ++r) {
+        acc[r] += R.m[r * 3] * o0 + R.m[r * 3 + 1] * o1 + R.m[r * 3 + 2] * o2;
+        myp[3 * j + r] = acc[r];
       }
     }
-    // ---- JPE sum and direct position grads (in place over the targets)
+  }
+  __syncthreads();
+
+  // ---- phase 2 (wave 0): absolute positions in chain order, JPE, direct + subtree-summed position gradients;
+  //      (wave 1, or 0 if there is only one): root loss
+  float jpe = 0.f, rl = 0.f;
+  if (wave == 0 && active) {
+    myp[0] = 0.f; myp[1] = 0.f; myp[2] = 0.f;
+    for (int c = 0; c < n_chains; ++c) {
+      const int cl = g.tree.chain_len[c];
+      const int head = g.tree.chain[c][0];
+      const float h0 = myp[3 * head], h1 = myp[3 * head + 1], h2 = myp[3 * head + 2];
+      for (int i = 1; i < cl; ++i) {
+        const int j = g.tree.chain[c][i];
+        myp[3 * j] += h0; myp[3 * j + 1] += h1; myp[3 * j + 2] += h2;
+      }
+    }
     for (int c = 0; c < J3; ++c) {
       const float d = myp[c] - myt[c];
       jpe += d * d;
       myt[c] = 2.f * g.jpe_scale * d;
     }
     if (do_bwd) {
-      // subtree sums: pose[c_i] depends on pose[c_{i-1}]
-      for (int ch = g.tree.n_chains - 1; ch >= 0; --ch) {
-        const int len = g.tree.chain_len[ch];
-        for (int i = len - 1; i >= 1; --i) {
-          const int j = g.tree.chain[ch][i], par = g.tree.chain[ch][i - 1];
+      for (int c = n_chains - 1; c >= 0; --c) {
+        const int cl = g.tree.chain_len[c];
+        for (int i = cl - 1; i >= 1; --i) {
+          const int j = g.tree.chain[c][i], par = g.tree.chain[c][i - 1];
 #pragma unroll
           for (int r = 0; r < 3; ++r) myt[3 * par + r] += myt[3 * j + r];
         }
       }
-      M3 dM0;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) dM0.m[k] = 0.f;
-      float a0[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) a0[k] = my[k];
-      for (int ch = 0; ch < g.tree.n_chains; ++ch) {
-        const int len = g.tree.chain_len[ch];
-        if (len < 2) continue;
-        // recompute the prefix products R_0..R_{len-2}
-        M3 Rs[SVAE_MAX_CHAIN_LEN - 1];
-        Rs[0] = M0;
-#pragma unroll
-        for (int i = 1; i < SVAE_MAX_CHAIN_LEN - 1; ++i) {
-          if (i < len - 1) {
-            const int j = g.tree.chain[ch][i];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) a6[k] = my[6 * j + k];
-            Rs[i] = mul(Rs[i - 1], c6_to_mat(a6));
-          }
-        }
-        M3 carry;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) carry.m[k] = 0.f;
-#pragma unroll
-        for (int i = SVAE_MAX_CHAIN_LEN - 1; i >= 1; --i) {
-          if (i < len) {
-            const int j = g.tree.chain[ch][i];
-            M3 D = carry;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-              for (int k = 0; k < 3; ++k) D.m[r * 3 + k] += myt[3 * j + r] * myo[3 * j + k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) a6[k] = my[6 * j + k];
-            const M3 Mj = c6_to_mat(a6);
-            const M3 dMj = mul_tn(Rs[i - 1], D);
-            carry = mul_nt(D, Mj);
-            float da[6];
-            c6_to_mat_bwd(a6, dMj, da);
-            // joints other than 0 occur once as a rotation: finish them here
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-              float gk = da[k];
-              if (g.ext_dx6d) gk += g.ext_dx6d[(r0 + lane) * C6 + 6 * j + k];
-              my[6 * j + k] = g.pre_tanh ? gk * (1.f - a6[k] * a6[k]) : gk;
-            }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) dM0.m[k] += carry.m[k];
-      }
-      float da0[6];
-      c6_to_mat_bwd(a0, dM0, da0);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        float gk = da0[k];
-        if (g.ext_dx6d) gk += g.ext_dx6d[(r0 + lane) * C6 + k];
-        my[k] = g.pre_tanh ? gk * (1.f - a0[k] * a0[k]) : gk;
-      }
-    }
-    if (g.has_arena) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float xh = my[C6 + k];
-        const float half = 0.5f * (g.a1[k] - g.a0[k]);
-        const float rh = (xh + 1.f) * half + g.a0[k];
-        const float d = rh - g.root[(r0 + lane) * 3 + k];
-        rl += d * d;
-        if (do_bwd) {
-          float gk = 2.f * g.root_scale * d;
-          if (g.ext_droot) gk += g.ext_droot[(r0 + lane) * 3 + k];
-          my[C6 + k] = g.pre_tanh ? gk * half * (1.f - xh * xh) : gk * half;
-        }
-      }
-    }
-    if (do_bwd) {
-      // joints never reached as a rotation keep tanh values in the tile: they get zero grad
-      // (handled on the host: the tree must cover every joint; see svae_pose_tail)
-      for (int c = C6 + (g.has_arena ? 3 : 0); c < g.ld; ++c) my[c] = 0.f;
     }
   }
-  jpe = wave_sum(jpe);
-  rl = wave_sum(rl);
-  if (lane == 0) {
-    g.loss_part[blockIdx.x * 2] = jpe;
-    g.loss_part[blockIdx.x * 2 + 1] = rl;
+  const int root_wave = nth > 64 ? 1 : 0;
+  if (wave == root_wave && active && g.has_arena) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float xh = my[C6 + k];
+      const float half = 0.5f * (g.a1[k] - g.a0[k]);
+      const float rh = (xh + 1.f) * half + g.a0[k];
+      const float d = rh - g.root[(r0 + lane) * 3 + k];
+      rl += d * d;
+      if (do_bwd) {
+        float gk = 2.f * g.root_scale * d;
+        if (g.ext_droot) gk += g.ext_droot[(r0 + lane) * 3 + k];
+        my[C6 + k] = g.pre_tanh ? gk * half * (1.f - xh * xh) : gk * half;
+      }
+    }
   }
+  if (wave == root_wave && active && do_bwd) {
+    for (int c = C6 + (g.has_arena ? 3 : 0); c < g.ld; ++c) my[c] = 0.f;  // padding columns carry no gradient
+  }
+  __syncthreads();
+
+  // ---- phase 3 (wave = chain): chain-product backward; joints i >= 1 of a chain occur once as a rotation
+  if (do_bwd && active && chain_wave) {
+    M3 Rs[SVAE_MAX_CHAIN_LEN - 1];
+    Rs[0] = M0;
+#pragma unroll
+    for (int i = 1; i < SVAE_MAX_CHAIN_LEN - 1; ++i) {
+      if (i < len - 1) {
+        const int j = g.tree.chain[ch][i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a6[k] = my[6 * j + k];
+        Rs[i] = mul(Rs[i - 1], c6_to_mat(a6));
+      }
+    }
+    M3 carry;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) carry.m[k] = 0.f;
+#pragma unroll
+    for (int i = SVAE_MAX_CHAIN_LEN - 1; i >= 1; --i) {
+      if (i < len) {
+        const int j = g.tree.chain[ch][i];
+        M3 D = carry;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) D.m[r * 3 + k] += myt[3 * j + r] * myo[3 * j + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a6[k] = my[6 * j + k];
+        const M3 Mj = c6_to_mat(a6);
+        const M3 dMj = mul_tn(Rs[i - 1], D);
+        carry = mul_nt(D, Mj);
+        float da[6];
+        c6_to_mat_bwd(a6, dMj, da);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          float gk = da[k];
+          if (g.ext_dx6d) gk += g.ext_dx6d[(r0 + lane) * C6 + 6 * j + k];
+          my[6 * j + k] = g.pre_tanh ? gk * (1.f - a6[k] * a6[k]) : gk;
+        }
+      }
+    }
+    float* d = dm0 + (ch * 64 + lane) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = carry.m[k];
+  }
+  if (do_bwd) __syncthreads();
+  if (do_bwd && wave == 0 && active) {  // joint 0: the root rotation collects every chain's carry (in chain order)
+    M3 dM0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dM0.m[k] = 0.f;
+    for (int c = 0; c < n_chains; ++c) {
+      if (g.tree.chain_len[c] < 2) continue;
+      const float* d = dm0 + (c * 64 + lane) * 9;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) dM0.m[k] += d[k];
+    }
+    float a0[6], da0[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a0[k] = my[k];
+    c6_to_mat_bwd(a0, dM0, da0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      float gk = da0[k];
+      if (g.ext_dx6d) gk += g.ext_dx6d[(r0 + lane) * C6 + k];
+      my[k] = g.pre_tanh ? gk * (1.f - a0[k] * a0[k]) : gk;
+    }
+  }
+  if (wave == 0) {
+    jpe = wave_sum(jpe);
+    if (lane == 0) g.loss_part[blockIdx.x * 2] = jpe;
+  }
+  if (wave == root_wave) {
+    rl = wave_sum(rl);
+    if (lane == 0) g.loss_part[blockIdx.x * 2 + 1] = rl;
+  }
+  __syncthreads();
   if (g.pose_out != nullptr) {
-    __syncthreads();
     float* dp = g.pose_out + r0 * J3;
-    for (int e = lane; e < nrows * J3; e += 64) {
+    for (int e = tid; e < nrows * J3; e += nth) {
       const int rr = e / J3, c = e - rr * J3;
       dp[e] = pose[rr * ldo + c];
     }
   }
   if (do_bwd) {
-    __syncthreads();
     const int f4_per_row = g.ld / 4;
     const int total = nrows * f4_per_row;
     float* dst = g.dy + r0 * g.ld;
-    for (int e = lane; e < total; e += 64) {
+    for (int e = tid; e < total; e += nth) {
       const int rr = e / f4_per_row, c = (e - rr * f4_per_row) * 4;
       const float* s = tile + rr * ldt + c;
       *reinterpret_cast<float4*>(dst + (long long)e * 4) = make_float4(s[0], s[1], s[2], s[3]);
@@ -471,14 +507,15 @@ extern "C" int svae_pose_tail(const float* y, int ld, const float* offsets, cons
     for (int k = 0; k < 3; ++k) { g.a0[k] = arena_host[k]; g.a1[k] = arena_host[3 + k]; }
   g.jpe_scale = jpe_scale; g.root_scale = root_scale;
   g.tree = *tree;
-  const size_t smem = (size_t)(64 * g.ldt + 3 * 64 * g.ldo) * sizeof(float);
+  const int n_waves = tree->n_chains >= 2 ? tree->n_chains : 2;
+  const size_t smem = (size_t)(64 * g.ldt + 3 * 64 * g.ldo + tree->n_chains * 64 * 9) * sizeof(float);
   SVAE_REQUIRE(smem <= 160 * 1024, SVAE_ERR_SHAPE, "pose_tail: LDS tile %zu B exceeds 160 KiB", smem);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)pose_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(pose_tail_kernel, dim3(svae_tail_blocks(rows)), dim3(64), smem, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(pose_tail_kernel, dim3(svae_tail_blocks(rows)), dim3(64 * n_waves), smem, (hipStream_t)stream, g);
   return check_launch("pose_tail");
 }
 

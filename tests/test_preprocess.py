@@ -24,9 +24,10 @@ def test_oracle_preprocess_matches_reference(golden_dir, name):
     fx, skel = load(golden_dir, name)
     win = P.get_window_indices(fx["raw_ids"], int(fx["stride"]), int(fx["window"]))
     out = P.preprocess_windows(fx["raw_pose"][win], skel["KINEMATIC_TREE"], skel["OFFSET"], KEYS, "midfwd", fwd_kin=O.fwd_kin)
+    # bit-identical on the machine that wrote the fixture; another CPU's vectorised fp32 paths move the last bits
     for k in KEYS:
         if k != "ids":
-            assert float((out[k].double() - torch.from_numpy(fx["out/" + k]).double()).abs().max()) <= 1e-6, k
+            assert float((out[k].double() - torch.from_numpy(fx["out/" + k]).double()).abs().max()) <= 1e-5, k
 
 
 @pytest.mark.gpu
