@@ -100,18 +100,39 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, double count,
 }
 
 // reduce the chunk partials AND finalize in one launch (single-rank path: no all-reduce between)
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, double count, int C,
+// 256 threads = 32 channels x 8 chunk-lanes: lane s of a channel sums chunks s, s+8, ... in fp64, the eight
+// lane sums are combined in lane order (deterministic); adjacent threads read adjacent channels.
+constexpr int FIN_SUB = 8, FIN_CH = 32;
+
+__device__ __forceinline__ bool chunk_sums(const float* __restrict__ part, int chunks, int C, int c, int sub, double& s0, double& s1,
+                                           double (*red)[FIN_SUB][FIN_CH]) {
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C)
+    for (int ch = sub; ch < chunks; ch += FIN_SUB) {
+      a0 += (double)part[((long long)ch * 2) * C + c];
+      a1 += (double)part[((long long)ch * 2 + 1) * C + c];
+    }
+  const int cl = threadIdx.x % FIN_CH;
+  red[0][sub][cl] = a0;
+  red[1][sub][cl] = a1;
+  __syncthreads();
+  if (sub != 0 || c >= C) return false;
+  s0 = 0.0; s1 = 0.0;
+#pragma unroll
+  for (int i = 0; i < FIN_SUB; ++i) { s0 += red[0][i][cl]; s1 += red[1][i][cl]; }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, double count, int C,
                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                          float* running_mean, float* running_var, long long* num_batches_tracked, float* mean_o,
                                          float* rstd_o, float* scale, float* shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int ch = 0; ch < chunks; ++ch) {
-    s0 += (double)part[((long long)ch * 2) * C + c];
-    s1 += (double)part[((long long)ch * 2 + 1) * C + c];
-  }
+  __shared__ double red[2][FIN_SUB][FIN_CH];
+  const int sub = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+  double s0, s1;
+  if (!chunk_sums(part, chunks, C, c, sub, s0, s1, red)) return;
   const double mean = s0 / count;
   double var = s1 / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -129,26 +150,30 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int chu
 }
 
 // backward: reduce the chunk partials to sums[2][C] and emit the parameter gradients
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ sums, float* dgamma,
-                                     float* dbeta, float* dalpha, const float* __restrict__ dalpha_part, int n_parts,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ sums,
+                                     float* dgamma, float* dbeta, float* dalpha, const float* __restrict__ dalpha_part, int n_parts,
                                      int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int ch = 0; ch < chunks; ++ch) {
-      s0 += (double)part[((long long)ch * 2) * C + c];
-      s1 += (double)part[((long long)ch * 2 + 1) * C + c];
+  __shared__ double red[2][FIN_SUB][FIN_CH];
+  __shared__ double dsum[256];
+  const int sub = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+  if (blockIdx.x == 0 && dalpha != nullptr) {  // PReLU slope: all partials, strided fp64 sums + fixed-order tree
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_parts; i += 256) acc += (double)dalpha_part[i];
+    dsum[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) dsum[threadIdx.x] += dsum[threadIdx.x + o];
+      __syncthreads();
     }
-    sums[c] = (float)s0;
-    sums[C + c] = (float)s1;
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s0;
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s1;
+    if (threadIdx.x == 0) dalpha[0] = (accumulate ? dalpha[0] : 0.f) + (float)dsum[0];
   }
-  if (c == 0 && dalpha != nullptr) {
-    double s = 0.0;
-    for (int i = 0; i < n_parts; ++i) s += (double)dalpha_part[i];
-    dalpha[0] = (accumulate ? dalpha[0] : 0.f) + (float)s;
-  }
+  double s0, s1;
+  if (!chunk_sums(part, chunks, C, c, sub, s0, s1, red)) return;
+  sums[c] = (float)s0;
+  sums[C + c] = (float)s1;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s0;
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s1;
 }
 
 __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -790,7 +815,7 @@ extern "C" int svae_bn_stats_finalize(const float* part, int n_chunks, double co
                                       void* stream) {
   SVAE_REQUIRE(part && gamma && beta && mean && rstd && scale && shift && count > 0 && n_chunks > 0, SVAE_ERR_ARG,
                "bn_stats_finalize: bad args");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), part, n_chunks, count, C, gamma,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, ST(stream), part, n_chunks, count, C, gamma,
                      beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale, shift);
   return check_launch("bn_stats_finalize");
 }
@@ -798,7 +823,7 @@ extern "C" int svae_bn_stats_finalize(const float* part, int n_chunks, double co
 extern "C" int svae_bn_bwd_reduce(const float* part, int n_chunks, int C, float* sums, float* dgamma, float* dbeta,
                                   float* dalpha, const float* dalpha_part, int n_parts, int accumulate, void* stream) {
   SVAE_REQUIRE(part && sums && n_chunks > 0 && (!dalpha || dalpha_part), SVAE_ERR_ARG, "bn_bwd_reduce: bad args");
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), part, n_chunks, C, sums, dgamma, dbeta,
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, ST(stream), part, n_chunks, C, sums, dgamma, dbeta,
                      dalpha, dalpha_part, n_parts, accumulate);
   return check_launch("bn_bwd_reduce");
 }
