@@ -210,7 +210,7 @@ def main():
             "value": round(B * world * args.steps / dt, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else f"f32 storage/accumulate, contractions as {args.precision} split on the bf16 matrix cores",
+            "dtype": "f32" if args.precision == "f32" else f"f32 ({args.precision} split on the bf16 matrix cores)",
             "data": "synthetic",
             "config": {"workload": ("configs[2] full SC-VAE (conditional + grad_reversal x2 + adversarial_net)" if args.full else
                                     "configs[1] mouse-skeleton rcnn, recon+KL (jpe+root+prior), AdamW") +
@@ -218,6 +218,10 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "window": args.window, "joints": args.joints,
                        "launch": "hipGraph replay" if args.graph else "eager launches",
                        "streams": "serialised" if args.serial_streams else "3 HIP streams (weight gradients / skip branches overlap the main chain)",
+                       "precision": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.precision == "f32" else
+                                     f"{args.precision}: fp32 storage and accumulation; every large contraction splits its fp32 operands into "
+                                     f"bf16 pieces and runs {PRODUCTS[args.precision]} cross product(s) on v_mfma_f32_32x32x16_bf16"
+                                     + (" (fp32-accurate, DESIGN.md 4)" if args.precision == "bf16x6" else " (reduced accuracy)")),
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("+localbn" if args.local_bn else "+syncbn")),
                        "final_total_loss": total_loss},
         }
