@@ -17,10 +17,14 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, ablation=False):
+    """ablation=True additionally compiles the timing-experiment kernel variants used by tools/bench_split_dbg.py
+    (parts of the work removed, wrong results) -- never part of the shipped library."""
     if not force and not needs_build():
         return OUT
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result"]
+    if ablation:
+        cmd.append("-DSVAE_ABLATION_KERNELS")
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
@@ -32,4 +36,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv or "--ablation" in sys.argv, verbose=True, ablation="--ablation" in sys.argv))

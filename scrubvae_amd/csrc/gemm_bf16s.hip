@@ -1109,6 +1109,7 @@ static void launch_split_ws(const SplitGatherArgs& sa, dim3 grid, hipStream_t st
   else hipLaunchKernelGGL((gather_gemm_bf16s_ws_kernel<BM, BN, 1, CWR, CWC, D>), grid, block, 0, st, sa);
 }
 
+#ifdef SVAE_ABLATION_KERNELS  // timing experiments with parts of the work removed (wrong results): python scrubvae_amd/build.py --ablation
 static void launch_split_dbg(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int dbg) {
   const dim3 block(64 * 12);
 #define SVAE_DBG_CASE(N) case N: hipLaunchKernelGGL((gather_gemm_bf16s_ws_kernel<128, 128, 3, 4, 2, 2, N>), grid, block, 0, st, sa); break;
@@ -1119,6 +1120,7 @@ static void launch_split_dbg(const SplitGatherArgs& sa, dim3 grid, hipStream_t s
   }
 #undef SVAE_DBG_CASE
 }
+#endif
 
 // upper bound of the halo image rows over all BM-row tiles of both phases
 static int halo_rows(const GatherArgs& g, int bm) {
@@ -1162,6 +1164,12 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
   if (bm == 0) return SVAE_OK;
   dim3 grid(bm, (g.N + t.bn - 1) / t.bn);
   const int v = t.dma;
+#ifdef SVAE_ABLATION_KERNELS
+#define SVAE_ABLATION_CASE(BM_, BN_) \
+  else if (v >= 10 && v < 26 && BM_ == 128 && BN_ == 128 && pieces == 3) launch_split_dbg(sa, grid, st, v - 10);
+#else
+#define SVAE_ABLATION_CASE(BM_, BN_)
+#endif
 #define SVAE_SPLIT_CASE(BM_, BN_)                                                          \
   if (t.bm == BM_ && t.bn == BN_) {                                                        \
     if (v == 0) launch_split_p<BM_, BN_, 2, 2, 2, 1>(sa, grid, st, pieces);                \
@@ -1175,7 +1183,7 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
     else if (v == 6 && BN_ == 128) launch_split_ws<64, 128, 2, 4, 3>(sa, grid, st, pieces);   \
     else if (v == 7) launch_split_ws<BM_, BN_, 2, 2, 3>(sa, grid, st, pieces);                \
     else if (v == 8 && BM_ == 128) { if (int e = launch_halo<BN_>(sa, grid, st, pieces, halo_rows(g, 128))) return e; } \
-    else if (v >= 10 && v < 26 && BM_ == 128 && BN_ == 128 && pieces == 3) launch_split_dbg(sa, grid, st, v - 10); \
+    SVAE_ABLATION_CASE(BM_, BN_)                                                           \
     else { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_ARG; } \
   }
   SVAE_SPLIT_CASE(128, 128) else SVAE_SPLIT_CASE(128, 64) else SVAE_SPLIT_CASE(64, 128) else SVAE_SPLIT_CASE(64, 64)

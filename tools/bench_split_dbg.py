@@ -1,4 +1,5 @@
-"""Timing experiments on the wave-specialised split kernel with parts of its work removed (results are wrong)."""
+"""Timing experiments on the wave-specialised split kernel with parts of its work removed (results are wrong).
+Needs the ablation variants: `python scrubvae_amd/build.py --ablation` first (and a plain rebuild afterwards)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
