@@ -635,3 +635,50 @@ def generative_restrictiveness(sd, cfg, z, data, key, rand):
         pred = torch.stack([root_spd, dxyz[0], (dxyz[1] + dxyz[2]) / 2], dim=-1)
         pred = (pred - torch.tensor(GEN_SPD_MEAN, dtype=dt)) / torch.tensor(GEN_SPD_STD, dtype=dt)
     return pred, data[key], data
+
+
+# ------------------------------------------------------- streaming scrubber
+def mals_init(nx, ny, bias=False, lamdiff=1e-1, dtype=torch.float32):
+    """MovingAvgLeastSquares.__init__, disentangle.py:393-438 (polynomial_order 1)."""
+    n = nx + int(bias)
+    return {"Sxx0": torch.eye(n, dtype=dtype), "Sxy0": torch.zeros(n, ny, dtype=dtype), "Sxx1": torch.eye(n, dtype=dtype),
+            "Sxy1": torch.zeros(n, ny, dtype=dtype), "lam0": torch.tensor([0.9], dtype=dtype),
+            "lam1": torch.tensor([0.9], dtype=dtype) + lamdiff, "bias": bias, "lamdiff": lamdiff}
+
+
+def _mals_design(st, x):
+    return torch.column_stack((x, torch.ones(x.shape[0], 1, dtype=x.dtype))) if st["bias"] else x
+
+
+def mals_forward(st, x, l2_reg=0.0):
+    """disentangle.py:467-492."""
+    x = _mals_design(st, x)
+    l2 = torch.ones(x.shape[1], dtype=x.dtype) * l2_reg
+    if st["bias"]:
+        l2[-1] = 0
+    W0 = torch.linalg.solve(st["Sxx0"].diagonal_scatter(st["Sxx0"].diagonal() + l2), st["Sxy0"])
+    W1 = torch.linalg.solve(st["Sxx1"].diagonal_scatter(st["Sxx1"].diagonal() + l2), st["Sxy1"])
+    return [x @ W0, x @ W1]
+
+
+def mals_update(st, x, y):
+    """disentangle.py:494-506 (returns the new state)."""
+    x = _mals_design(st, x)
+    xx, xy = (x.T @ x).detach(), (x.T @ y).detach()
+    st = dict(st)
+    st["Sxx0"], st["Sxy0"] = st["lam0"] * st["Sxx0"] + xx, st["lam0"] * st["Sxy0"] + xy
+    st["Sxx1"], st["Sxy1"] = st["lam1"] * st["Sxx1"] + xx, st["lam1"] * st["Sxy1"] + xy
+    return st
+
+
+def mals_loss(st, yhat0, yhat1, y, delta=1e-4):
+    """disentangle.py:508-538: returns ((l0 + l1) / 2, new state with the forgetting factors moved)."""
+    l0, l1 = ((y - yhat0) ** 2).sum(), ((y - yhat1) ** 2).sum()
+    st = dict(st)
+    if l0 < l1:
+        st["lam0"] = torch.clamp(st["lam0"] - delta, 0.0, 1.0)
+        st["lam1"] = st["lam0"] + st["lamdiff"]
+    else:
+        st["lam1"] = torch.clamp(st["lam1"] + delta, 0.0, 1.0)
+        st["lam0"] = st["lam1"] - st["lamdiff"]
+    return (l0 + l1) * 0.5, st

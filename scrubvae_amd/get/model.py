@@ -9,7 +9,7 @@ FEAT_DIMS = {"avg_speed": 1, "part_speed": 4, "avg_speed_3d": 3, "heading": 2, "
 
 def model(model_config, load_model, epoch, disentangle_config, n_keypts, direction_process, loss_config=None,
           arena_size=None, kinematic_tree=None, bound=False, discrete_classes=None, device="cuda", verbose=1):
-    from scrubvae_amd.model.disentangle import GRScrubber, AdvNetScrubber
+    from scrubvae_amd.model.disentangle import GRScrubber, AdvNetScrubber, MovingAvgLeastSquares
     from scrubvae_amd.model.residual import ResVAE
 
     feat_dim_dict = dict(FEAT_DIMS)
@@ -22,7 +22,7 @@ def model(model_config, load_model, epoch, disentangle_config, n_keypts, directi
         in_channels += 3
 
     methods = disentangle_config["method"] or {}
-    for unsupported in ("linear", "moving_avg_lsq", "qda", "moving_avg", "direct_lsq"):
+    for unsupported in ("linear", "qda", "moving_avg", "direct_lsq"):
         if unsupported in methods:
             raise NotImplementedError(
                 f"disentangle method '{unsupported}' is outside this build's scope (SURVEY.md 8a row A2 / 8f N4)")
@@ -40,6 +40,12 @@ def model(model_config, load_model, epoch, disentangle_config, n_keypts, directi
     if "adversarial_net" in methods:
         disentangle["adversarial_net"] = {
             feat: AdvNetScrubber(model_config["z_dim"] + conditional_dim) for feat in methods["adversarial_net"]}
+
+    if "moving_avg_lsq" in methods:  # get/model.py:73-84
+        disentangle["moving_avg_lsq"] = {
+            feat: MovingAvgLeastSquares(model_config["z_dim"], feat_dim_dict[feat], bias=loss_config[feat + "_mals"] < 0,
+                                        polynomial_order=disentangle_config["polynomial"], l2_reg=disentangle_config["l2_reg"])
+            for feat in methods["moving_avg_lsq"]}
 
     if model_config["type"] != "rcnn":
         raise ValueError("only model.type == 'rcnn' exists (reference get/model.py:116)")

@@ -127,3 +127,80 @@ class EnsembleRunner:
                     ops.relu_bwd(prev["g"], prev["act"], prev["g"])
                     g = prev["g"]
         return self.g_in
+
+
+class MovingAvgLeastSquares(nn.Module):
+    """Streaming closed-form linear scrubber (reference: disentangle.py:393-538).
+
+    Two exponentially-forgetting covariance pairs (Sxx, Sxy) with forgetting factors lam0 < lam1 = lam0 + lamdiff;
+    forward solves both normal equations and predicts y from the latent means, `evaluate_loss` returns the mean of
+    the two squared errors and nudges the forgetting factors toward the better decoder, `update` folds a batch into
+    the covariances.  These are [z x z] solves and [B x z] products on device tensors -- stock torch ops behind the
+    reference API, as SURVEY 8a allows for this row; the gradient into the encoder is seeded analytically by
+    train.losses (the decoders W are constants of the step).  polynomial_order > 1 is not built."""
+
+    def __init__(self, nx, ny, lamdiff=1e-1, delta=1e-4, bias=False, polynomial_order=1, l2_reg=0):
+        super().__init__()
+        if polynomial_order != 1:
+            raise NotImplementedError("MovingAvgLeastSquares: polynomial_order > 1 is not built (SURVEY 8f N4)")
+        self.bias = bool(bias)
+        self.polynomial_order = 1
+        self.nx_in = int(nx)
+        nx = int(nx) + int(self.bias)
+        self.l2_reg = 0 if l2_reg is None else l2_reg
+        print("Moving Avg Least Squares Bias: {}".format(self.bias))
+        self.register_buffer("Sxx0", torch.eye(nx))
+        self.register_buffer("Sxy0", torch.zeros(nx, ny))
+        self.register_buffer("Sxx1", torch.eye(nx))
+        self.register_buffer("Sxy1", torch.zeros(nx, ny))
+        self.register_buffer("lam0", torch.tensor([0.9]))
+        self.register_buffer("lam1", self.lam0 + lamdiff)
+        self.delta = delta
+        self.lamdiff = lamdiff
+        self.process_group = None  # set by parallel.attach: batch statistics are summed over the ranks
+        self._W = None
+
+    def _design(self, x):
+        x = x[:, : self.nx_in]
+        if self.bias:
+            x = torch.column_stack((x, torch.ones(x.shape[0], 1, device=x.device)))
+        return x
+
+    def forward(self, x):
+        x = self._design(x)
+        l2 = torch.ones(x.shape[1], device=x.device) * self.l2_reg
+        if self.bias:
+            l2[-1] = 0
+        W0 = torch.linalg.solve(self.Sxx0.diagonal_scatter(self.Sxx0.diagonal() + l2), self.Sxy0)
+        W1 = torch.linalg.solve(self.Sxx1.diagonal_scatter(self.Sxx1.diagonal() + l2), self.Sxy1)
+        self._W = (W0, W1)
+        return [x @ W0, x @ W1]
+
+    def _allreduce(self, t):
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+        return t
+
+    def update(self, x, y):
+        x = self._design(x)
+        xx = self._allreduce((x.T @ x).detach())
+        xy = self._allreduce((x.T @ y.to(x.dtype)).detach())
+        self.Sxx0 = self.lam0 * self.Sxx0 + xx
+        self.Sxy0 = self.lam0 * self.Sxy0 + xy
+        self.Sxx1 = self.lam1 * self.Sxx1 + xx
+        self.Sxy1 = self.lam1 * self.Sxy1 + xy
+        return self
+
+    def evaluate_loss(self, yhat0, yhat1, y):
+        """(l0 + l1) / 2 with l = summed squared error (disentangle.py:505-538); the forgetting factors move by
+        `delta` toward the better decoder (on device, no host sync; the sums are global under data parallelism)."""
+        y = y.to(yhat0.dtype)
+        l = torch.stack([((y - yhat0) ** 2).sum(), ((y - yhat1) ** 2).sum()])
+        lg = self._allreduce(l.detach().clone())
+        down = lg[0] < lg[1]
+        lam0_dn = torch.clamp(self.lam0 - self.delta, 0.0, 1.0)
+        lam1_up = torch.clamp(self.lam1 + self.delta, 0.0, 1.0)
+        self.lam0 = torch.where(down, lam0_dn, lam1_up - self.lamdiff)
+        self.lam1 = torch.where(down, lam0_dn + self.lamdiff, lam1_up)
+        return (l[0] + l[1]) * 0.5

@@ -657,6 +657,8 @@ class ResVAE(nn.Module):
                     x[:, self.z_dim: self.z_dim + self.conditional_dim] = data_o["var"]
                     outs = self._runner(method + ".fwd", k, m.ensemble, B).forward(x)
                     data_o["disentangle"][method][k] = [torch.softmax(o[:, :2], -1) for o in outs]
+                elif method == "moving_avg_lsq":
+                    data_o["disentangle"][method][k] = m(mu[:, : self.z_dim])
                 else:
                     raise NotImplementedError(f"scrubber '{method}' is outside this build's scope (SURVEY 8a row A2)")
         self._state = dict(B=B, flat=flat, h=h, eps=eps, mu=mu, sigma=sigma, zc=zc, klp=klp, data=data)

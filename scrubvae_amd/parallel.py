@@ -57,6 +57,10 @@ def attach(model, process_group=None, sync_bn=True, broadcast=True):
     model.rank = dist.get_rank(process_group)
     model.process_group = process_group
     model.sync_bn = sync_bn
+    for mods in getattr(model, "disentangle", {}).values():  # streaming scrubbers sum their batch statistics over the ranks
+        for m in mods.values():
+            if hasattr(m, "process_group"):
+                m.process_group = process_group
     if broadcast and model.world_size > 1:
         dist.broadcast(model.flat_params, src=0, group=process_group)
         for b in model.buffers():

@@ -41,7 +41,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     Bg = B * world  # losses are normalised by the GLOBAL batch so that summed grads match 1 GPU
     train = model.training and torch.is_grad_enabled()
     for k in loss_scale.keys():
-        if k in SUPPORTED or k.endswith("_gr") or k.endswith("_an"):
+        if k in SUPPORTED or k.endswith("_gr") or k.endswith("_an") or k.endswith("_mals"):
             continue
         raise NotImplementedError(f"loss '{k}' is outside this build's scope (SURVEY 8a: L5/A2 rows)")
     batch_loss = {}
@@ -169,6 +169,20 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 add_total(lk, vv)
                 if train and loss_scale[lk] != 0:
                     scrub.append(dict(kind="an", runner=runner, d_outs=d_outs))
+            elif method == "moving_avg_lsq":  # losses.py:237-246
+                m = model.disentangle[method][key]
+                lk = key + "_mals"
+                y0, y1 = data_o["disentangle"][method][key]
+                tgt = model._prep(data[key])
+                v = _scalar(model, lk)
+                v.copy_((m.evaluate_loss(y0, y1, tgt) / Bg).reshape(1))
+                batch_loss[lk] = v.view(()).clone()
+                if lk in loss_scale:
+                    add_total(lk, v)
+                    if train and loss_scale[lk] != 0:  # d/d mu of scale * (l0 + l1) / (2 Bg), decoders W constant
+                        W0, W1 = m._W
+                        zin = m.nx_in
+                        d_mu[:, :zin] += (float(loss_scale[lk]) / Bg) * ((y0 - tgt) @ W0[:zin].T + (y1 - tgt) @ W1[:zin].T)
             else:
                 raise NotImplementedError(f"scrubber '{method}' is outside this build's scope (SURVEY 8a row A2)")
 

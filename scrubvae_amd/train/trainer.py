@@ -187,6 +187,11 @@ def train_test_epoch(config, model, loader, device, epoch, optimizer=None, sched
                 optimizer.step()
                 if scheduler is not None:
                     scheduler.step(epoch + batch_idx / len(loader))
+                # update the exponential-moving-average scrubbers (trainer.py:170-180)
+                for method in model.disentangle.keys():
+                    if method in ["moving_avg_lsq", "moving_avg", "qda"]:
+                        for k in model.disentangle[method].keys():
+                            model.disentangle[method][k].update(data_o["mu"].detach().clone(), data[k].detach().clone())
             epoch_metrics = {k: v + batch_loss[k].detach() for k, v in epoch_metrics.items()}
             n_batches += 1
         for k, v in epoch_metrics.items():

@@ -118,3 +118,48 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("scvae_oracle", "oracle").split("import")[-1] or "from oracle" not in src, f
                 assert "from oracle" not in src and "import oracle" not in src, f
+
+
+def _mals_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    parallel.init_distributed(backend="gloo")
+    try:
+        from scrubvae_amd.model.disentangle import MovingAvgLeastSquares
+        g = torch.Generator().manual_seed(1)
+        x, y = torch.randn(16, 8, generator=g), torch.randn(16, 3, generator=g)
+        lo, hi = parallel.shard_range(16, rank, world)
+        m = MovingAvgLeastSquares(8, 3, bias=True)
+        for _ in range(3):
+            y0, y1 = m(x[lo:hi])
+            m.evaluate_loss(y0, y1, y[lo:hi])
+            m.update(x[lo:hi], y[lo:hi])
+        q.put((rank, {k: v.numpy() for k, v in m.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_streaming_scrubber_matches_one_rank():
+    """MovingAvgLeastSquares sums its batch statistics (x^T x, x^T y and the two squared errors that steer the
+    forgetting factors) over the ranks: 2 ranks with half batches end with the buffers of 1 rank with the batch."""
+    from scrubvae_amd.model.disentangle import MovingAvgLeastSquares
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(16, 8, generator=g), torch.randn(16, 3, generator=g)
+    ref = MovingAvgLeastSquares(8, 3, bias=True)
+    for _ in range(3):
+        y0, y1 = ref(x)
+        ref.evaluate_loss(y0, y1, y)
+        ref.update(x, y)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mals_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        for k, v in ref.state_dict().items():
+            assert torch.allclose(torch.from_numpy(res[r][k]), v, rtol=1e-5, atol=1e-6), (r, k)
