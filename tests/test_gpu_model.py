@@ -331,3 +331,30 @@ def test_test_epoch_runs_and_matches_oracle_losses(golden_dir):
     assert rel(z, O.encode(sd, cfg, data, False)["mu"]) < 5e-5
     for key in ("avg_speed_3d", "heading"):
         assert np.isfinite(metrics[f"r2_gen_restrict_{key}"])
+
+
+# ------------------------------------------------------------------ split-bf16 precision on the whole model
+@pytest.fixture
+def bf16x6_everywhere():
+    """Every conv / linear of the model on the split-bf16 kernels (3 pieces, 6 products), whatever its size."""
+    from scrubvae_amd import ops
+    keep = (ops.PRECISION, ops.SPLIT_MIN_FLOPS)
+    ops.set_precision("bf16x6")
+    ops.SPLIT_MIN_FLOPS = 0.0
+    yield
+    ops.set_precision(keep[0])
+    ops.SPLIT_MIN_FLOPS = keep[1]
+
+
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "fullL_ids_tiny", "vanilla_default_B4"])
+def test_step0_matches_reference_fixture_bf16x6(golden_dir, name, bf16x6_everywhere):
+    """The reference fixtures at the SAME fp32 tolerances with the contractions on the bf16 matrix cores
+    (bench.py's default precision): the 3-piece split is fp32-accurate, not a reduced-precision mode."""
+    test_step0_matches_reference_fixture(golden_dir, name)
+
+
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny"])
+def test_three_steps_and_grads_bf16x6(golden_dir, name, bf16x6_everywhere):
+    """Gradients vs the fp64 truth and three optimizer steps + eval forward, same gates as the fp32 kernels."""
+    test_grads_vs_fp64_truth(golden_dir, name)
+    test_three_steps_and_eval(golden_dir, name)
