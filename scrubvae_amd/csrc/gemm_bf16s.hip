@@ -753,27 +753,35 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
       arow[mt] = ro[mt] + tb;  // image row = a(m) - amin + (base - bmin)
       aval[mt] = (unsigned)(jj[mt] + tb) < (unsigned)g.Lin;
     }
+    // operand fragments of BOTH 16-deep k-steps are requested up front (one exposed LDS latency per stage, then 2 x
+    // MT x NT x 6 MFMAs back to back); padding rows are zeroed with an AND mask (a select on the loaded value would be
+    // turned into a divergent branch around the ds_read)
+    uint4 av[2][MT][P], bv[2][NT][P];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      uint4 av[MT][P], bv[NT][P];
       const int ch = ks * 2 + h;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        const unsigned mask = aval[mt] ? 0xffffffffu : 0u;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          const uint4 v = *reinterpret_cast<const uint4*>(smem + p * A_PIECE + arow[mt] * ROWB + ((ch ^ swz(arow[mt])) << 4));
-          av[mt][p] = aval[mt] ? v : make_uint4(0u, 0u, 0u, 0u);
+          uint4 v = *reinterpret_cast<const uint4*>(smem + p * A_PIECE + arow[mt] * ROWB + ((ch ^ swz(arow[mt])) << 4));
+          v.x &= mask; v.y &= mask; v.z &= mask; v.w &= mask;
+          av[ks][mt][p] = v;
         }
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int p = 0; p < P; ++p)
-          bv[nt][p] = *reinterpret_cast<const uint4*>(bst + p * B_PIECE + b_addr[nt] + ((ch ^ b_sw[nt]) << 4));
+          bv[ks][nt][p] = *reinterpret_cast<const uint4*>(bst + p * B_PIECE + b_addr[nt] + ((ch ^ b_sw[nt]) << 4));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_split<P>(av[mt], bv[nt], acc[mt][nt]);
-    }
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_split<P>(av[ks][mt], bv[ks][nt], acc[mt][nt]);
   };
 
   if (ns > 0) {
