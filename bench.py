@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
-PRODUCTS = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "bf16": 1}  # matrix-core products per algorithmic multiply
+PRODUCTS = {"f32": 1, "bf16x6": 6, "bf16x6w3": 6, "bf16x3": 3, "bf16": 1}  # matrix-core products per algorithmic multiply (fwd / dgrad)
 
 
 def parse():
@@ -46,9 +46,11 @@ def parse():
     ap.add_argument("--full", action="store_true", help="configs[2]: conditional + grad-reversal + adversarial heads")
     ap.add_argument("--local-bn", action="store_true", help="per-rank BatchNorm statistics (no sync-BN collectives)")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph (single GPU)")
-    ap.add_argument("--precision", default=os.environ.get("SVAE_PRECISION", "bf16x6"), choices=list(PRODUCTS),
+    ap.add_argument("--precision", default=os.environ.get("SVAE_PRECISION", "bf16x6w3"), choices=list(PRODUCTS),
                     help="arithmetic of the large contractions: f32 = fp32 MFMA; bf16x6 = fp32-accurate 3-piece split on the bf16 "
-                         "matrix cores (6 products); bf16x3 / bf16 = 2 / 1 pieces (reduced accuracy, not a headline mode)")
+                         "matrix cores (6 products); bf16x6w3 = the same with 2 pieces / 3 products for the weight-gradient "
+                         "contractions (gradient error vs fp64 unchanged, DESIGN.md 4); bf16x3 / bf16 = 2 / 1 pieces everywhere "
+                         "(reduced accuracy, study only)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="timed region without the concurrent side streams (what the roofline region always uses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -221,7 +223,9 @@ def main():
                        "precision": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.precision == "f32" else
                                      f"{args.precision}: fp32 storage and accumulation; every large contraction splits its fp32 operands into "
                                      f"bf16 pieces and runs {PRODUCTS[args.precision]} cross product(s) on v_mfma_f32_32x32x16_bf16"
-                                     + (" (fp32-accurate, DESIGN.md 4)" if args.precision == "bf16x6" else " (reduced accuracy)")),
+                                     + (" (fp32-accurate, DESIGN.md 4)" if args.precision == "bf16x6" else
+                                        " forward and data-gradient (fp32-accurate), 3 (2 pieces) for the weight-gradient contractions "
+                                        "(gradient error vs fp64 unchanged, DESIGN.md 4)" if args.precision == "bf16x6w3" else " (reduced accuracy)")),
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("+localbn" if args.local_bn else "+syncbn")),
                        "final_total_loss": total_loss},
         }

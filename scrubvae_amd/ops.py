@@ -86,8 +86,13 @@ _KIND_ID = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 # products run on the bf16 matrix cores with fp32 accumulation (csrc/gemm_bf16s.hip); bf16x6
 # is as accurate as f32.  Read when a Conv is constructed; convs below SPLIT_MIN_FLOPS stay f32.
 PRECISION = os.environ.get("SVAE_PRECISION", "f32")
-_PIECES = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1}
-SPLIT_MIN_FLOPS = float(os.environ.get("SVAE_SPLIT_MIN_FLOPS", 1e9))
+_PIECES = {"f32": 0, "bf16x6": 3, "bf16x6w3": 3, "bf16x3": 2, "bf16": 1}
+# "bf16x6w3": forward / data-gradient contractions with 3 pieces (6 products), WEIGHT-gradient contractions with 2
+# pieces (3 products).  A weight gradient sums >= thousands of rows; its own 2^-16-per-product rounding is invisible
+# next to the error the forward / data-gradient arithmetic already leaves on the same tensor
+# (tests/studies/precision_bf16_split.py: worst gradient error vs fp64 identical to bf16x6, 3-7x below fp32's own).
+_WGRAD_PIECES = {"bf16x6w3": 2}
+SPLIT_MIN_FLOPS = float(os.environ.get("SVAE_SPLIT_MIN_FLOPS", 2e9))
 # VBBBNNN: V = 0: 4 waves, double-buffered LDS; 1: 4 waves, one LDS buffer; 2 / 3: 8 waves (BM = 128), one / two buffers
 # 4: wave-specialised (4 producer + 8 consumer waves); 5: wave-specialised 4 + 4
 _SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2128064, 3128128, 3128064)
@@ -165,6 +170,8 @@ class Conv:
         self.flops = 2.0 * batch * (l_in if transposed else l_out) * kernel * c_in * c_out
         # bf16 pieces per operand (0 = fp32 MFMA kernels)
         self.pieces = (_PIECES[PRECISION] if self.flops >= SPLIT_MIN_FLOPS else 0) if pieces is None else int(pieces)
+        # pieces of the weight-gradient contraction (differs from self.pieces only in the "bf16x6w3" precision)
+        self.wgrad_pieces = (_WGRAD_PIECES.get(PRECISION, self.pieces) if self.pieces else 0) if pieces is None else int(pieces)
         self._wsplit, self._split_epoch, self._split_src = None, -1, None
 
     def split_weights(self, w):
@@ -179,8 +186,11 @@ class Conv:
 
     _F32_FLAG = 100000000  # table / log encoding: "this kind of this split-precision conv runs the fp32 kernel <code % flag>"
 
+    def _base_pieces(self, kind):
+        return self.wgrad_pieces if kind == "wgrad" else self.pieces
+
     def _kind_pieces(self, kind):
-        return self.__dict__.get("_kp", {}).get(kind, self.pieces)
+        return self.__dict__.get("_kp", {}).get(kind, self._base_pieces(kind))
 
     def _set_choice(self, kind, pieces, code):
         self.__dict__.setdefault("_kp", {})[kind] = pieces
@@ -196,19 +206,20 @@ class Conv:
             return
         tuned.add(kind)
         d = self.desc
-        key = f"{kind}{'@' + str(self.pieces) if self.pieces else ''}:{d.batch}:{d.l_in}:{d.c_in}:{d.c_out}:{d.ld_in}:{d.ld_out}:{d.kernel}:{d.stride}:{d.padding}:{d.transposed}"
+        base = self._base_pieces(kind)
+        key = f"{kind}{'@' + str(base) if base else ''}:{d.batch}:{d.l_in}:{d.c_in}:{d.c_out}:{d.ld_in}:{d.ld_out}:{d.kernel}:{d.stride}:{d.padding}:{d.transposed}"
         if key in TILE_TABLE:
             v = int(TILE_TABLE[key])
-            self._set_choice(kind, 0 if v >= self._F32_FLAG else self.pieces, v % self._F32_FLAG)
+            self._set_choice(kind, 0 if v >= self._F32_FLAG else base, v % self._F32_FLAG)
             return
         if not AUTOTUNE or self.flops < AUTOTUNE_MIN_FLOPS or torch.cuda.is_current_stream_capturing():
             return
         cands = []
-        if self.pieces:
-            cands += [(self.pieces, c) for c in (_SPLIT_WGRAD_CODES if kind == "wgrad" else _SPLIT_GATHER_CODES)]
-        if not self.pieces or (self.pieces == 3 and MIX_F32):
+        if base:
+            cands += [(base, c) for c in (_SPLIT_WGRAD_CODES if kind == "wgrad" else _SPLIT_GATHER_CODES)]
+        if not base or (MIX_F32 and (base == 3 or (kind == "wgrad" and self.pieces == 3))):
             cands += [(0, c) for c in (_WGRAD_CODES if kind == "wgrad" else _GATHER_CODES)]
-        best, best_t = (self.pieces, 0), float("inf")
+        best, best_t = (base, 0), float("inf")
         for pieces, code in cands:
             self._set_choice(kind, pieces, code)
             try:
@@ -226,7 +237,7 @@ class Conv:
             if t < best_t * 0.98:  # candidates are ordered large -> small: ties keep the larger tile
                 best, best_t = (pieces, code), t
         self._set_choice(kind, *best)
-        TUNED_LOG[key] = best[1] + (self._F32_FLAG if (self.pieces and not best[0]) else 0)
+        TUNED_LOG[key] = best[1] + (self._F32_FLAG if (base and not best[0]) else 0)
 
     def kernel_name(self, kind):
         """Name of the kernel template instance this call dispatches to (as rocprofv3 prints it)."""

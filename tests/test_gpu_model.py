@@ -334,12 +334,14 @@ def test_test_epoch_runs_and_matches_oracle_losses(golden_dir):
 
 
 # ------------------------------------------------------------------ split-bf16 precision on the whole model
-@pytest.fixture
-def bf16x6_everywhere():
-    """Every conv / linear of the model on the split-bf16 kernels (3 pieces, 6 products), whatever its size."""
+@pytest.fixture(params=["bf16x6", "bf16x6w3"])
+def bf16x6_everywhere(request):
+    """Every conv / linear of the model on the split-bf16 kernels, whatever its size: 3 pieces / 6 products
+    ("bf16x6"), and the same with 2 pieces / 3 products for the weight-gradient contractions ("bf16x6w3",
+    bench.py's default)."""
     from scrubvae_amd import ops
     keep = (ops.PRECISION, ops.SPLIT_MIN_FLOPS)
-    ops.set_precision("bf16x6")
+    ops.set_precision(request.param)
     ops.SPLIT_MIN_FLOPS = 0.0
     yield
     ops.set_precision(keep[0])

@@ -8,10 +8,11 @@ from scrubvae_amd.data import synthetic
 from scrubvae_amd.get import model as get_model
 from scrubvae_amd.train.losses import get_batch_loss
 
+table = dict(ops.TILE_TABLE) if "--keep" in sys.argv else {}
+sys.argv = [a for a in sys.argv if a != "--keep"]
 ops.TILE_TABLE = {}
 ops.AUTOTUNE_REPS = 12
-table = {}
-PRECISIONS = sys.argv[1:] or ["f32", "bf16x6"]
+PRECISIONS = sys.argv[1:] or ["f32", "bf16x6", "bf16x6w3"]
 for prec, joints, batch, full in [(p, *c) for p in PRECISIONS
                                   for c in ((23, 1024, False), (23, 1024, True), (23, 4096, False), (18, 1024, False), (23, 256, False))]:
     ops.set_precision(prec)
@@ -33,6 +34,7 @@ for prec, joints, batch, full in [(p, *c) for p in PRECISIONS
         bl["total"].backward()
     torch.cuda.synchronize()
     table.update(ops.TUNED_LOG)
+    ops.TILE_TABLE = dict(table)  # geometries tuned by an earlier precision in this run are not re-timed
     print(f"{prec} J={joints} B={batch} full={full}: {len(ops.TUNED_LOG)} geometries tuned so far", flush=True)
     del m
     torch.cuda.empty_cache()
