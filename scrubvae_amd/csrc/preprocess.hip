@@ -9,8 +9,7 @@
 //   speed_parts_kernel  dataset.py:133-163 (get_speed_parts) + :373-375 (limbs averaged)
 //
 // HBM-bound, fp32 (the reference computes the pose differences in float64 numpy and every quaternion helper in
-// float32 torch).  One thread per frame: a frame is 3J floats in and 12J + 3 out; the per-thread strided rows are
-// served from L2 (a frame's row is contiguous), so no LDS staging in this first version.
+// float32 torch).  A frame is 3J floats in and 12J + 3 out.
 #include "svae_internal.h"
 
 namespace svae {
@@ -69,76 +68,109 @@ struct InvKinArgs {
   svae_tree tree;
 };
 
-__global__ __launch_bounds__(256) void inv_kin_kernel(const InvKinArgs g) {
-  const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (f >= g.frames) return;
-  const int J = g.J;
-  const float* p = g.pose + f * J * 3;
-  const long long win = f / g.window;
-  const float* pm = g.pose + (win * g.window + g.window / 2) * J * 3;  // middle frame of this window
+// One workgroup per 64 consecutive frames, one wave per kinematic chain (lane = frame): every chain starts from the
+// frame's root quaternion, so the chains are independent.  The pose rows come in and the x6d / offset rows go out
+// through LDS tiles with fully coalesced accesses (a block of 64 frames is one contiguous span of each array; the
+// odd row strides make the lane-per-frame phase bank-conflict free).
+__global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void inv_kin_kernel(const InvKinArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int J = g.J, J3 = 3 * J, J6 = 6 * J;
+  const int ldp = J3 | 1, ldx = J6 | 1;
+  float* tp = smem;             // [64][ldp] pose
+  float* tx = tp + 64 * ldp;    // [64][ldx] x6d
+  float* to = tx + 64 * ldx;    // [64][ldp] offsets
+  const long long f0 = (long long)blockIdx.x * 64;
+  const int nf = (int)((g.frames - f0) < 64 ? (g.frames - f0) : 64);
 
-  // yaw of the middle frame (get_frame_yaw(root_i=0, front_i=1))
-  float fw[3] = {pm[3] - pm[0], pm[4] - pm[1], pm[5] - pm[2]};
-  normalize3(fw);
-  const float yaw = -atan2f(fw[1], fw[0]);
-  if (g.heading && f == win * g.window) {
-    g.heading[win * 2] = sinf(yaw);
-    g.heading[win * 2 + 1] = cosf(yaw);
+  for (int e = tid; e < nf * J3; e += nth) {
+    const int rr = e / J3, c = e - rr * J3;
+    tp[rr * ldp + c] = g.pose[f0 * J3 + e];
   }
-  const Q4 fwd_q = {cosf(0.5f * yaw), 0.f, 0.f, sinf(0.5f * yaw)};
+  __syncthreads();
 
-  // root quaternion: forward_indices = [1, 0] -> pose[0] - pose[1], rotated onto +x; frame 0 of the array is identity
-  float fr[3] = {p[0] - p[3], p[1] - p[4], p[2] - p[5]};
-  normalize3(fr);
-  const float ex[3] = {1.f, 0.f, 0.f};
-  Q4 root_q = qbetween(fr, ex);
-  if (f == 0) root_q = Q4{1.f, 0.f, 0.f, 0.f};
-
-  float* out = g.x6d + f * J * 6;
-  {
-    const Q4 q0 = g.midfwd ? qmul(fwd_q, root_q) : root_q;
-    q_to_cont6d(q0, out);
-  }
-  for (int c = 0; c < g.tree.n_chains; ++c) {
-    Q4 R = root_q;
-    const int len = g.tree.chain_len[c];
-    for (int i = 0; i + 1 < len; ++i) {
-      const int a = g.tree.chain[c][i], b = g.tree.chain[c][i + 1];
-      float v[3] = {p[3 * b] - p[3 * a], p[3 * b + 1] - p[3 * a + 1], p[3 * b + 2] - p[3 * a + 2]};
-      normalize3(v);
-      const Q4 rot = qbetween(g.uoff[b], v);
-      const Q4 loc = qmul(qinv(R), rot);
-      q_to_cont6d(loc, out + 6 * b);
-      R = qmul(R, loc);
-    }
-  }
-  if (g.offsets) {
-    float* o = g.offsets + f * J * 3;
-    o[0] = g.uoff[0][0]; o[1] = g.uoff[0][1]; o[2] = g.uoff[0][2];
-    for (int j = 1; j < J; ++j) {
-      const int a = g.parent[j];
-      const float d[3] = {p[3 * j] - p[3 * a], p[3 * j + 1] - p[3 * a + 1], p[3 * j + 2] - p[3 * a + 2]};
-      const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const bool active = lane < nf;
+  const long long f = f0 + lane;
+  const float* p = tp + lane * ldp;
+  if (active) {
+    const long long win = f / g.window;
+    const float* pm = g.pose + (win * g.window + g.window / 2) * J3;  // middle frame of this window (may be outside the tile)
+    float fw[3] = {pm[3] - pm[0], pm[4] - pm[1], pm[5] - pm[2]};
+    normalize3(fw);
+    const float yaw = -atan2f(fw[1], fw[0]);
+    const Q4 fwd_q = {cosf(0.5f * yaw), 0.f, 0.f, sinf(0.5f * yaw)};
+    // root quaternion: forward_indices = [1, 0] -> pose[0] - pose[1], rotated onto +x; frame 0 of the array is identity
+    float fr[3] = {p[0] - p[3], p[1] - p[4], p[2] - p[5]};
+    normalize3(fr);
+    const float ex[3] = {1.f, 0.f, 0.f};
+    Q4 root_q = qbetween(fr, ex);
+    if (f == 0) root_q = Q4{1.f, 0.f, 0.f, 0.f};
+    float* out = tx + lane * ldx;
+    if (wave == 0) {
+      if (g.heading && f == win * g.window) {
+        g.heading[win * 2] = sinf(yaw);
+        g.heading[win * 2 + 1] = cosf(yaw);
+      }
+      const Q4 q0 = g.midfwd ? qmul(fwd_q, root_q) : root_q;
+      q_to_cont6d(q0, out);
+      if (g.root) {
+        float r[3] = {p[0], p[1], p[2]};
+        if (g.centre_root) { r[0] -= pm[0]; r[1] -= pm[1]; }
+        if (g.midfwd) {  // qrot(fwd_q, r), quaternion.py:55-74
+          const float qv[3] = {fwd_q.x, fwd_q.y, fwd_q.z};
+          const float uv[3] = {qv[1] * r[2] - qv[2] * r[1], qv[2] * r[0] - qv[0] * r[2], qv[0] * r[1] - qv[1] * r[0]};
+          const float uuv[3] = {qv[1] * uv[2] - qv[2] * uv[1], qv[2] * uv[0] - qv[0] * uv[2], qv[0] * uv[1] - qv[1] * uv[0]};
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float v = len * g.uoff[j][k];
-        o[3 * j + k] = g.truncate_len ? truncf(v) : v;
+          for (int k = 0; k < 3; ++k) r[k] = r[k] + 2.f * (fwd_q.w * uv[k] + uuv[k]);
+        }
+        float* ro = g.root + f * 3;
+        ro[0] = r[0]; ro[1] = r[1]; ro[2] = r[2];
+      }
+    }
+    for (int c = wave; c < g.tree.n_chains; c += (nth >> 6)) {
+      Q4 R = root_q;
+      const int len = g.tree.chain_len[c];
+      for (int i = 0; i + 1 < len; ++i) {
+        const int a = g.tree.chain[c][i], b = g.tree.chain[c][i + 1];
+        float v[3] = {p[3 * b] - p[3 * a], p[3 * b + 1] - p[3 * a + 1], p[3 * b + 2] - p[3 * a + 2]};
+        normalize3(v);
+        const Q4 rot = qbetween(g.uoff[b], v);
+        const Q4 loc = qmul(qinv(R), rot);
+        q_to_cont6d(loc, out + 6 * b);
+        R = qmul(R, loc);
       }
     }
   }
-  if (g.root) {
-    float r[3] = {p[0], p[1], p[2]};
-    if (g.centre_root) { r[0] -= pm[0]; r[1] -= pm[1]; }
-    if (g.midfwd) {  // qrot(fwd_q, r), quaternion.py:55-74
-      const float qv[3] = {fwd_q.x, fwd_q.y, fwd_q.z};
-      const float uv[3] = {qv[1] * r[2] - qv[2] * r[1], qv[2] * r[0] - qv[0] * r[2], qv[0] * r[1] - qv[1] * r[0]};
-      const float uuv[3] = {qv[1] * uv[2] - qv[2] * uv[1], qv[2] * uv[0] - qv[0] * uv[2], qv[0] * uv[1] - qv[1] * uv[0]};
+  if (g.offsets) {  // get_segment_len: one (frame, joint) per thread-iteration
+    for (int e = tid; e < nf * J; e += nth) {
+      const int rr = e / J, j = e - rr * J;
+      const float* q = tp + rr * ldp;
+      float* o = to + rr * ldp + 3 * j;
+      if (j == 0) {
+        o[0] = g.uoff[0][0]; o[1] = g.uoff[0][1]; o[2] = g.uoff[0][2];
+      } else {
+        const int a = g.parent[j];
+        const float d0 = q[3 * j] - q[3 * a], d1 = q[3 * j + 1] - q[3 * a + 1], d2 = q[3 * j + 2] - q[3 * a + 2];
+        const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) r[k] = r[k] + 2.f * (fwd_q.w * uv[k] + uuv[k]);
+        for (int k = 0; k < 3; ++k) {
+          const float v = len * g.uoff[j][k];
+          o[k] = g.truncate_len ? truncf(v) : v;
+        }
+      }
     }
-    float* ro = g.root + f * 3;
-    ro[0] = r[0]; ro[1] = r[1]; ro[2] = r[2];
   }
+  __syncthreads();
+  for (int e = tid; e < nf * J6; e += nth) {
+    const int rr = e / J6, c = e - rr * J6;
+    g.x6d[f0 * J6 + e] = tx[rr * ldx + c];
+  }
+  if (g.offsets)
+    for (int e = tid; e < nf * J3; e += nth) {
+      const int rr = e / J3, c = e - rr * J3;
+      g.offsets[f0 * J3 + e] = to[rr * ldp + c];
+    }
 }
 
 // get_speed_parts: one wave per window.  out[win][3] = [root speed, spine+head, mean(arms, legs)].
@@ -222,7 +254,10 @@ extern "C" int svae_inv_kin(const float* pose, const float* unit_offset_host, co
   }
   for (int j = 0; j < g.J; ++j)
     for (int k = 0; k < 3; ++k) g.uoff[j][k] = unit_offset_host[3 * j + k];
-  hipLaunchKernelGGL(inv_kin_kernel, dim3((unsigned)((frames + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g);
+  const int n_waves = tree->n_chains >= 2 ? tree->n_chains : 2;
+  const int J3 = 3 * g.J, J6 = 6 * g.J;
+  const size_t smem = (size_t)64 * (2 * (J3 | 1) + (J6 | 1)) * sizeof(float);
+  hipLaunchKernelGGL(inv_kin_kernel, dim3((unsigned)((frames + 63) / 64)), dim3(64 * n_waves), smem, (hipStream_t)stream, g);
   return check_launch("inv_kin");
 }
 
