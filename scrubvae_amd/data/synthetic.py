@@ -37,10 +37,13 @@ def fwd_kin_cont6d(x6d, kinematic_tree, offsets):
     HIP tail kernel.  x6d [..., J, 6], offsets [..., J, 3] -> pose [..., J, 3]."""
     J = x6d.shape[-2]
     rows = x6d.numel() // (6 * J)
-    ld = ops.pad16(6 * J)
     dev = x6d.device
-    xin = torch.zeros(rows, ld, device=dev)
-    xin[:, : 6 * J] = x6d.reshape(rows, 6 * J)
+    if (6 * J) % 4 == 0 and x6d.is_contiguous() and x6d.dtype == torch.float32 and x6d.data_ptr() % 16 == 0:
+        ld, xin = 6 * J, x6d.reshape(rows, 6 * J)  # the kernel only needs float4-aligned rows: no padded copy
+    else:
+        ld = ops.pad16(6 * J)
+        xin = torch.zeros(rows, ld, device=dev)
+        xin[:, : 6 * J] = x6d.reshape(rows, 6 * J)
     offs = offsets.reshape(rows, J, 3).float().contiguous()
     pose = torch.empty(rows, J, 3, device=dev)
     scratch6 = torch.empty(rows, 6 * J, device=dev)
