@@ -74,6 +74,14 @@ int svae_conv_fwd(const svae_conv_desc* d, const float* x, const float* w, const
 /* dx (+)= conv_backward_input(dy, w)      (autograd of the above) */
 int svae_conv_dgrad(const svae_conv_desc* d, const float* dy, const float* w, float* dx,
                     int accumulate, void* stream);
+/* The same two calls with an optional split-K workspace (the Linear heads: few output tiles, long reduction): partial
+ * tiles go to `ws` (svae_conv_splitk_workspace(d, kind) bytes, kind 0 = fwd / 1 = dgrad; 0 = no split for this
+ * geometry) and are summed in a fixed order.  ws == NULL or too small: identical to the calls above. */
+size_t svae_conv_splitk_workspace(const svae_conv_desc* d, int kind);
+int svae_conv_fwd_ws(const svae_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                     int accumulate, void* ws, size_t ws_bytes, void* stream);
+int svae_conv_dgrad_ws(const svae_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
+                       void* ws, size_t ws_bytes, void* stream);
 /* dw (+)= conv_backward_weight(x, dy); split-K partial slabs in `ws`, reduced in a fixed
  * order (bit-reproducible).  db (optional, may be NULL) (+)= column sums of dy. */
 size_t svae_conv_wgrad_workspace(const svae_conv_desc* d);

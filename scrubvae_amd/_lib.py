@@ -65,6 +65,9 @@ SIGNATURES = {
     "svae_conv_fwd": (I, [DP, P, P, P, P, I, P]),
     "svae_conv_dgrad": (I, [DP, P, P, P, I, P]),
     "svae_conv_wgrad_workspace": (SZ, [DP]),
+    "svae_conv_splitk_workspace": (SZ, [DP, I]),
+    "svae_conv_fwd_ws": (I, [DP, P, P, P, P, I, P, SZ, P]),
+    "svae_conv_dgrad_ws": (I, [DP, P, P, P, I, P, SZ, P]),
     "svae_conv_wgrad": (I, [DP, P, P, P, P, P, SZ, I, P]),
     "svae_conv_tile": (I, [DP, I, C.POINTER(I), C.POINTER(I)]),
     "svae_conv_split_bytes": (SZ, [DP]),

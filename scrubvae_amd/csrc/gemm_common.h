@@ -22,6 +22,10 @@ struct GatherArgs {
   long long w_tap_stride;
   int N;  // padded output channels
   int accumulate;
+  // split-K (fp32 gather kernel, single-phase plans with few output tiles): blockIdx.z handles K tiles
+  // [z*nk/ksplit, (z+1)*nk/ksplit) and writes its partial tile to slab[z][m][N]; splitk_reduce adds them in z order
+  int ksplit;
+  float* slab;
 };
 
 inline int validate(const svae_conv_desc* d) {

@@ -94,15 +94,20 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
   }
 
   const int tiles_per_tap = (g.Kc + GBK - 1) / GBK;  // the last tile of a tap may be half full
-  const int nk = ntaps * tiles_per_tap;
+  const int nk_all = ntaps * tiles_per_tap;
+  // split-K: this block's share of the K tiles
+  const int ks = g.ksplit > 1 ? g.ksplit : 1;
+  const int kt_begin = (int)((long long)nk_all * blockIdx.z / ks);
+  const int nk = (int)((long long)nk_all * (blockIdx.z + 1) / ks) - kt_begin;
 
   float4 ra[APASS], rb[BPASS];
   bool ra_ok[APASS], rb_ok[BPASS];  // zero-fill is applied when the tile is written to LDS
   // tap bookkeeping is advanced incrementally and one tile AHEAD of its use, so that the
   // scalar loads of the tap table never sit in front of the global loads / MFMAs
-  int nx_c0 = 0, nx_ti = 0;
-  int nx_tb = ntaps > 0 ? tap_base[0] : 0;
-  long long nx_woff = ntaps > 0 ? (long long)tap_w[0] * g.w_tap_stride : 0;
+  int nx_ti = kt_begin / tiles_per_tap;
+  int nx_c0 = (kt_begin - nx_ti * tiles_per_tap) * GBK;
+  int nx_tb = ntaps > 0 ? tap_base[nx_ti < ntaps ? nx_ti : ntaps - 1] : 0;
+  long long nx_woff = ntaps > 0 ? (long long)tap_w[nx_ti < ntaps ? nx_ti : ntaps - 1] * g.w_tap_stride : 0;
   auto load_tile = [&]() {
     const int c0 = nx_c0;
     const int tb = nx_tb;
@@ -239,6 +244,22 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs g) {
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+  if (g.ksplit > 1) {  // partial tile -> slab[z][m][N] (bias / accumulate are applied by splitk_reduce_kernel)
+    float* slab = g.slab + (long long)blockIdx.z * Mp * g.N;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + wc * WN + nt * 32 + lr;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long m = m0 + wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < Mp) slab[m * g.N + col] = acc[mt][nt][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = n0 + wc * WN + nt * 32 + lr;
@@ -843,16 +864,59 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int chunks, 
   out[c] = (accumulate ? out[c] : 0.f) + (float)s;
 }
 
+// C[m][col] (+)= bias[col] + sum_z slab[z][m][col]   (fixed z order; single-phase plans: row m of C is m*ldC)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                            float* __restrict__ C, long long M, int N, int ldC, int ksplit, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * N) return;
+  const long long m = i / N;
+  const int col = (int)(i - m * N);
+  float v = bias ? bias[col] : 0.f;
+  float s = 0.f;
+  for (int z = 0; z < ksplit; ++z) s += slab[(long long)z * M * N + i];
+  v += s;
+  float* dst = C + m * ldC + col;
+  if (accumulate) v += *dst;
+  *dst = v;
+}
+
+// split-K factor for skinny problems (few output tiles, long K): 0 = do not split
+static int splitk_factor(const GatherArgs& g, int bm, int bn) {
+  if (g.n_phase != 1 || g.nj[0] != g.Lout) return 0;
+  const long long tiles = ((g.M[0] + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+  const int nk = g.ntaps[0] * ((g.Kc + GBK - 1) / GBK);
+  if (tiles >= 128 || nk < 16) return 0;
+  long long ks = 512 / tiles;
+  if (ks > nk / 4) ks = nk / 4;
+  if (ks > 64) ks = 64;
+  return ks >= 2 ? (int)ks : 0;
+}
+
 // -------------------------------------------------------------------------- host side
 
 template <bool B_KC>
-static int launch_gather_auto(GatherArgs& g, hipStream_t st, int override_code) {
+static int launch_gather_auto(GatherArgs& g, hipStream_t st, int override_code, void* ws = nullptr, size_t ws_bytes = 0) {
   Tile t;
   if (!decode_tile(override_code, t)) t = pick_tile(g.M[0], g.M[1], g.N);
   for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + t.bm - 1) / t.bm);
   const int bm = g.blocks_m[0] + g.blocks_m[1];
   if (bm == 0) return SVAE_OK;
   dim3 grid(bm, (g.N + t.bn - 1) / t.bn);
+  if (ws != nullptr) {  // split-K for skinny problems when the caller provides the slab workspace
+    const int ks = splitk_factor(g, 64, 64);
+    if (ks >= 2 && ws_bytes >= (size_t)ks * g.M[0] * g.N * sizeof(float)) {
+      g.ksplit = ks;
+      g.slab = (float*)ws;
+      g.blocks_m[0] = (int)((g.M[0] + 63) / 64);
+      dim3 sgrid(g.blocks_m[0], (g.N + 63) / 64, ks);
+      hipLaunchKernelGGL((gather_gemm_kernel<64, 64, B_KC>), sgrid, dim3(256), 0, st, g);
+      if (int e = check_launch("gather_gemm(split-K)")) return e;
+      const long long n = g.M[0] * g.N;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g.slab, g.bias, g.C, g.M[0], g.N,
+                         g.ldC, ks, g.accumulate);
+      return check_launch("splitk_reduce");
+    }
+  }
   if (t.dma) {
     if (t.bm == 128 && t.bn == 128) hipLaunchKernelGGL((gather_gemm_dma_kernel<128, 128, B_KC>), grid, dim3(256), 0, st, g);
     else if (t.bm == 128 && t.bn == 64) hipLaunchKernelGGL((gather_gemm_dma_kernel<128, 64, B_KC>), grid, dim3(256), 0, st, g);
@@ -885,6 +949,51 @@ extern "C" int svae_conv_fwd(const svae_conv_desc* d, const float* x, const floa
   g.accumulate = accumulate;
   build_plan(g, d, /*strided=*/!d->transposed, d->l_out, d->l_in);
   return launch_gather_auto<false>(g, (hipStream_t)stream, d->tile[0]);
+}
+
+// ---- the same two calls with an optional split-K workspace: problems with few output tiles and a long reduction
+// (the Linear heads: M = batch rows, N = z) are split over K into `svae_conv_splitk_workspace` bytes of partial
+// tiles that are summed in a fixed order.  ws == NULL or too small: identical to svae_conv_fwd / svae_conv_dgrad.
+extern "C" size_t svae_conv_splitk_workspace(const svae_conv_desc* d, int kind) {
+  if (validate(d) || (kind != 0 && kind != 1)) return 0;
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  if (kind == 0) { g.Kc = d->c_in; g.N = d->c_out; build_plan(g, d, !d->transposed, d->l_out, d->l_in); }
+  else { g.Kc = d->c_out; g.N = d->c_in; build_plan(g, d, d->transposed != 0, d->l_in, d->l_out); }
+  const int ks = splitk_factor(g, 64, 64);
+  return ks >= 2 ? (size_t)ks * g.M[0] * g.N * sizeof(float) : 0;
+}
+
+extern "C" int svae_conv_fwd_ws(const svae_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                                int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SVAE_REQUIRE(x && w && y, SVAE_ERR_ARG, "conv_fwd: null pointer");
+  SVAE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(ws), SVAE_ERR_ALIGN, "conv_fwd: pointers must be 16-byte aligned");
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = x; g.W = w; g.bias = bias; g.C = y;
+  g.Kc = d->c_in; g.ldA = d->ld_in; g.ldC = d->ld_out; g.ldW = d->c_out;
+  g.w_tap_stride = (long long)d->c_in * d->c_out;
+  g.N = d->c_out;
+  g.accumulate = accumulate;
+  build_plan(g, d, /*strided=*/!d->transposed, d->l_out, d->l_in);
+  return launch_gather_auto<false>(g, (hipStream_t)stream, d->tile[0], ws, ws_bytes);
+}
+
+extern "C" int svae_conv_dgrad_ws(const svae_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  SVAE_REQUIRE(dy && w && dx, SVAE_ERR_ARG, "conv_dgrad: null pointer");
+  SVAE_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws), SVAE_ERR_ALIGN, "conv_dgrad: pointers must be 16-byte aligned");
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = dy; g.W = w; g.bias = nullptr; g.C = dx;
+  g.Kc = d->c_out; g.ldA = d->ld_out; g.ldC = d->ld_in; g.ldW = d->c_out;
+  g.w_tap_stride = (long long)d->c_in * d->c_out;
+  g.N = d->c_in;
+  g.accumulate = accumulate;
+  build_plan(g, d, /*strided=*/d->transposed != 0, d->l_in, d->l_out);
+  return launch_gather_auto<true>(g, (hipStream_t)stream, d->tile[1], ws, ws_bytes);
 }
 
 extern "C" int svae_conv_dgrad(const svae_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,

@@ -285,11 +285,24 @@ class Conv:
             self._ws_bytes = int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc)))
         return self._ws_bytes
 
+    def _splitk_ws(self, kind_id, device):
+        """Slab workspace of the fp32 split-K path (skinny problems: the Linear heads), or None when the library
+        would not split this geometry.  Owned by the Conv (launches of one Conv are stream-ordered)."""
+        cache = self.__dict__.setdefault("_skws", {})
+        if kind_id not in cache:
+            n = int(_lib.lib().svae_conv_splitk_workspace(C.byref(self.desc), kind_id))
+            cache[kind_id] = torch.empty(n // 4 + 16, device=device) if n > 0 else None
+        return cache[kind_id]
+
     def _launch_fwd(self, x, w, bias, y, acc):
         kp = self._kind_pieces("fwd")
         if kp:
             return check(_lib.lib().svae_conv_fwd_split(C.byref(self.desc), _p(x), _p(self.split_weights(w)), _p(bias), _p(y),
                                                          acc, kp, _stream()), "conv_fwd_split")
+        ws = self._splitk_ws(0, x.device)
+        if ws is not None:
+            return check(_lib.lib().svae_conv_fwd_ws(C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), acc, _p(ws), ws.numel() * 4,
+                                                     _stream()), "conv_fwd_ws")
         return check(_lib.lib().svae_conv_fwd(C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), acc, _stream()), "conv_fwd")
 
     def _launch_dgrad(self, dy, w, dx, acc):
@@ -297,6 +310,10 @@ class Conv:
         if kp:
             return check(_lib.lib().svae_conv_dgrad_split(C.byref(self.desc), _p(dy), _p(self.split_weights(w)), _p(dx),
                                                            acc, kp, _stream()), "conv_dgrad_split")
+        ws = self._splitk_ws(1, dy.device)
+        if ws is not None:
+            return check(_lib.lib().svae_conv_dgrad_ws(C.byref(self.desc), _p(dy), _p(w), _p(dx), acc, _p(ws), ws.numel() * 4,
+                                                       _stream()), "conv_dgrad_ws")
         return check(_lib.lib().svae_conv_dgrad(C.byref(self.desc), _p(dy), _p(w), _p(dx), acc, _stream()), "conv_dgrad")
 
     def _launch_wgrad(self, x, dy, dw, db, ws, acc):
