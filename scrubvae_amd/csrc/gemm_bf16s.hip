@@ -12,13 +12,17 @@
 //           matrix-core time;
 //   P = 2 : 3 MFMAs (error O(2^-16));   P = 1 : plain bf16 operands (error O(2^-8)).
 //
-// Activations stay fp32 in HBM and are split on the way into LDS (11 VALU per pair of elements,
-// hidden in the MFMA issue gaps); weights are split once per optimizer step by
-// split_weights_kernel into K-contiguous piece planes for both uses:
-//   Wf[piece][tap][c_out][c_in]  (forward: k = c_in)      Wd[piece][tap][c_in][c_out]  (dgrad: k = c_out)
-// so the weight operand needs no conversion and no transposed LDS read in the GEMM.
-// LDS image of a tile: [piece][row][SBK] bf16, 16-byte chunks XOR-swizzled by the row so that
-// the ds_read_b128 operand fetches are conflict-free without padding.
+// Activations stay fp32 in HBM and are split on the way into LDS (11 VALU per pair of elements);
+// weights are split once per pass by split_weights(_batched)_kernel into piece planes pre-tiled in the
+// order the GEMMs stage them, for both uses:
+//   Wf[piece][tap][c_in/32][c_out][32]  (forward: k = c_in)     Wd[piece][tap][c_out/32][c_in][32]  (dgrad: k = c_out)
+// so the weight operand needs no conversion, no transposed LDS read, and loads as contiguous 128-byte lines.
+// LDS image of a tile: [piece][row][32 k] bf16, 16-byte chunks XOR-swizzled by the row so that the
+// ds_read_b128 operand fetches are conflict-free without padding.
+//
+// Kernels: gather_gemm_bf16s_kernel (A tile re-staged per tap; 4 / 8 waves, single / double LDS buffer),
+// gather_gemm_bf16s_ws_kernel (producer / consumer waves), gather_halo_bf16s_kernel (one A image per channel
+// block shared by all taps), wgrad_gemm_bf16s_kernel (both operands transposed into LDS), split_weights*.
 #include "gemm_common.h"
 #include <type_traits>
 
