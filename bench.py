@@ -174,6 +174,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         bl = step()
+    t_host = time.perf_counter() - t0  # all launches of the K steps are queued (the GPU is still working)
     barrier()
     dt = time.perf_counter() - t0
     # ---- roofline region: the same K steps again with the side streams serialised and HIP
@@ -226,6 +227,7 @@ def main():
                                      + (" (fp32-accurate, DESIGN.md 4)" if args.precision == "bf16x6" else
                                         " forward and data-gradient (fp32-accurate), 3 (2 pieces) for the weight-gradient contractions "
                                         "(gradient error vs fp64 unchanged, DESIGN.md 4)" if args.precision == "bf16x6w3" else " (reduced accuracy)")),
+                       "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("+localbn" if args.local_bn else "+syncbn")),
                        "final_total_loss": total_loss},
         }
