@@ -97,13 +97,38 @@ def cpu_baseline(args, method, feats, loss, sample_b=128, steps=3):
     eps = torch.randn(sample_b, cfg.z_dim)
     perm = {k: torch.randperm(sample_b) for k in cfg.method.get("adversarial_net", [])}
     state = {}
-    O.train_step(sd, cfg, data, loss, eps, adv_perm=perm, opt_state=state)  # warm-up
+    bl0, _, _, _ = O.train_step(sd, cfg, data, loss, eps, adv_perm=perm, opt_state=state)  # warm-up; also the ELBO reference
+    elbo = elbo_check(args, cfg, sd, data, eps, perm, loss, method, feats, bl0)
     t0 = time.perf_counter()
     for _ in range(steps):
         _, _, sd, _ = O.train_step(sd, cfg, data, loss, eps, adv_perm=perm, opt_state=state)
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(sample_b / dt, 2), "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} optimizer steps of the CPU oracle at batch {sample_b} (same model/loss config), {dt*1e3:.0f} ms/step"}
+            "sample": f"{steps} optimizer steps of the CPU oracle at batch {sample_b} (same model/loss config), {dt*1e3:.0f} ms/step",
+            "elbo_match": elbo}
+
+
+def elbo_check(args, cfg, sd, data, eps, perm, loss, method, feats, oracle_losses):
+    """The "ELBO-match" condition of the metric, checked on the benchmark's own model size and precision: the oracle's
+    weights, batch and noise on the HIP path; relative deviation of every loss term (bound: 1e-4)."""
+    from scrubvae_amd.get import model as get_model
+    from scrubvae_amd.train.losses import get_batch_loss
+    mc = dict(type="rcnn", kernel=5, z_dim=32, window=args.window, activation="prelu", diag=True, init_dilation=None,
+              prior="gaussian", channel=CHANNELS)
+    dis = dict(method=method, alpha=1.0, features=feats)
+    m = get_model(mc, None, None, dis, args.joints, "midfwd", arena_size=torch.tensor(ARENA), kinematic_tree=cfg.kinematic_tree,
+                  discrete_classes=cfg.discrete_classes, device="cuda", verbose=0)
+    m.load_state_dict(sd, strict=False)
+    m.train()
+    d = {k: v.cuda() for k, v in data.items()}
+    d["eps"] = eps.cuda()
+    bl = get_batch_loss(m, d, m(d), loss, dis, adv_perm=perm or None)
+    rel = {k: abs(float(bl[k].detach()) - float(v.detach())) / (abs(float(v.detach())) + 1e-30) for k, v in oracle_losses.items()}
+    worst = max(rel.values())
+    del m
+    torch.cuda.empty_cache()
+    return {"batch": int(eps.shape[0]), "precision": args.precision, "max_rel_dev_of_loss_terms_vs_cpu_oracle": float(f"{worst:.3g}"),
+            "total_rel_dev": float(f"{rel['total']:.3g}"), "bound": 1e-4, "ok": bool(worst <= 1e-4)}
 
 
 def pmc_traffic(kernel):
