@@ -362,3 +362,55 @@ def test_three_steps_and_grads_bf16x6(golden_dir, name, bf16x6_everywhere):
     """Gradients vs the fp64 truth and three optimizer steps + eval forward, same gates as the fp32 kernels."""
     test_grads_vs_fp64_truth(golden_dir, name)
     test_three_steps_and_eval(golden_dir, name)
+
+
+# ------------------------------------------------------------------ full benchmark size: size-independent properties
+def _bench_size_model(precision, seed=0):
+    from scrubvae_amd import ops
+    from scrubvae_amd.get import model as get_model
+    keep = ops.PRECISION
+    ops.set_precision(precision)
+    try:
+        cfg = O.OracleConfig(n_keypts=23, window=64, z_dim=32, kernel=5, diag=True, arena_size=ARENA, kinematic_tree=O.skeleton_tree(23))
+        sd = O.init_state_dict(cfg, seed=seed)
+        m, dis = build_model(cfg, sd)
+    finally:
+        ops.set_precision(keep)
+    return m, dis
+
+
+def test_full_size_properties_b1024():
+    """BASELINE configs[1] size (B=1024, W=64, J=23, default channels), where the CPU oracle is too slow to be the
+    checker: (a) the step is deterministic (two evaluations are bitwise equal), (b) eval-mode outputs are per-sample
+    (a batch permutation permutes them), (c) the three precisions of the HIP path agree on every loss term far
+    inside the 1e-4 ELBO bound, (d) the first half of the batch evaluated alone gives the same outputs."""
+    from scrubvae_amd.data import synthetic
+    from scrubvae_amd.train.losses import get_batch_loss
+    data, tree = synthetic.make_batch(23, 64, 1024, seed=3, device="cuda")
+    data = {k: v for k, v in data.items() if k in ("x6d", "root", "offsets", "target_pose")}
+    data["eps"] = torch.randn(1024, 32, generator=torch.Generator().manual_seed(1)).cuda()
+    ls = {"jpe": 1.0, "root": 1.0, "prior": 1.0}
+    losses = {}
+    for precision in ("f32", "bf16x6", "bf16x6w3"):
+        m, dis = _bench_size_model(precision)
+        m.train()
+        with torch.no_grad():
+            a = get_batch_loss(m, data, m(data), ls, dis)
+            b = get_batch_loss(m, data, m(data), ls, dis)
+        losses[precision] = {k: float(v) for k, v in a.items()}
+        assert all(float(a[k]) == float(b[k]) for k in a), precision                      # (a)
+        if precision == "bf16x6w3":
+            m.eval()
+            with torch.no_grad():
+                o = m(data)
+                x6d, mu = o["x6d"].clone(), o["mu"].clone()
+                perm = torch.randperm(1024, generator=torch.Generator().manual_seed(2)).cuda()
+                op = m({k: v[perm] for k, v in data.items()})
+                assert rel(op["x6d"].cpu(), x6d[perm].cpu()) < 2e-5 and rel(op["mu"].cpu(), mu[perm].cpu()) < 2e-5   # (b)
+                oh = m({k: v[:512] for k, v in data.items()})
+                assert rel(oh["x6d"].cpu(), x6d[:512].cpu()) < 2e-5                       # (d)
+        del m
+        torch.cuda.empty_cache()
+    for precision in ("bf16x6", "bf16x6w3"):                                              # (c)
+        for k, v in losses["f32"].items():
+            assert abs(losses[precision][k] - v) <= 1e-5 * abs(v), (precision, k, losses[precision][k], v)
