@@ -84,7 +84,7 @@ def build_model(args, method, feats, tree):
     return m, dis
 
 
-def cpu_baseline(args, method, feats, loss, sample_b=128, steps=3):
+def cpu_baseline(args, method, feats, loss, sample_b=128, steps=50):
     """cpu_baseline leg: the CPU oracle's train_step (the only place bench.py touches oracle/)
     on a bounded sample (sample_b windows) of the same workload."""
     from oracle import scvae_oracle as O
