@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
 }
 
 // --------------------------------------------------------------------------- BN stats
-constexpr int STAT_ROWS = 512;
+constexpr int STAT_ROWS = 128;  // rows per block of the BatchNorm partial-sum kernels (512 gave only 128 blocks per layer: 1.5 TB/s)
 
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long long rows, int C, int ld,
                                                                 float* __restrict__ part) {
