@@ -274,17 +274,33 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_apply_kernel(
     const int c = (int)(i - r * C4) * 4;
     const float4 xv4 = ld4(x + r * ld + c), dv4 = ld4(dy + r * ld + c);
     const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+    // per-channel coefficients as float4 loads (C and c are multiples of 4): 7 vector loads instead of 28 scalar ones
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (scale != nullptr) {
+      const float4 a4 = ld4(scale + c), b4 = ld4(shift + c);
+      sc[0] = a4.x; sc[1] = a4.y; sc[2] = a4.z; sc[3] = a4.w;
+      sh[0] = b4.x; sh[1] = b4.y; sh[2] = b4.z; sh[3] = b4.w;
+    }
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f},
+          s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sums != nullptr) {
+      const float4 m4 = ld4(mean + c), r4 = ld4(rstd + c), g4 = ld4(gamma + c), p4 = ld4(sums + c), q4 = ld4(sums + C + c);
+      mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+      rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
+      gm[0] = g4.x; gm[1] = g4.y; gm[2] = g4.z; gm[3] = g4.w;
+      s0[0] = p4.x; s0[1] = p4.y; s0[2] = p4.z; s0[3] = p4.w;
+      s1[0] = q4.x; s1[1] = q4.y; s1[2] = q4.z; s1[3] = q4.w;
+    }
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float sc = scale ? scale[c + k] : 1.f, sh = scale ? shift[c + k] : 0.f;
-      const float u = xv[k] * sc + sh;
+      const float u = xv[k] * sc[k] + sh[k];
       const float du = u > 0.f ? dv[k] : a * dv[k];
       if (sums != nullptr) {
-        const float xh = (xv[k] - mean[c + k]) * rstd[c + k];
-        o[k] = gamma[c + k] * rstd[c + k] * (du - sums[c + k] * inv_count - xh * sums[C + c + k] * inv_count);
+        const float xh = (xv[k] - mu[k]) * rs[k];
+        o[k] = gm[k] * rs[k] * (du - s0[k] * inv_count - xh * s1[k] * inv_count);
       } else {
-        o[k] = du * sc;
+        o[k] = du * sc[k];
       }
     }
     st4(dx + r * ld + c, make_float4(o[0], o[1], o[2], o[3]));
