@@ -102,7 +102,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, double count,
 // reduce the chunk partials AND finalize in one launch (single-rank path: no all-reduce between)
 // 256 threads = 32 channels x 8 chunk-lanes: lane s of a channel sums chunks s, s+8, ... in fp64, the eight
 // lane sums are combined in lane order (deterministic); adjacent threads read adjacent channels.
-constexpr int FIN_SUB = 8, FIN_CH = 32;
+constexpr int FIN_SUB = 32, FIN_CH = 8;
 
 __device__ __forceinline__ bool chunk_sums(const float* __restrict__ part, int chunks, int C, int c, int sub, double& s0, double& s1,
                                            double (*red)[FIN_SUB][FIN_CH]) {
@@ -307,17 +307,24 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_apply_kernel(
   }
 }
 
-__global__ void bn_param_grads_kernel(const float* __restrict__ sums, int C, float* dgamma, float* dbeta, float* dalpha,
+__global__ __launch_bounds__(128) void bn_param_grads_kernel(const float* __restrict__ sums, int C, float* dgamma, float* dbeta, float* dalpha,
                                       const float* __restrict__ dalpha_part, int n_parts, int accumulate) {
+  __shared__ double dsum[128];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (sums != nullptr && c < C) {
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + sums[c];
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + sums[C + c];
   }
-  if (c == 0 && dalpha != nullptr) {
-    double s = 0.0;
-    for (int i = 0; i < n_parts; ++i) s += (double)dalpha_part[i];
-    dalpha[0] = (accumulate ? dalpha[0] : 0.f) + (float)s;
+  if (blockIdx.x == 0 && dalpha != nullptr) {  // strided fp64 sums + fixed-order tree (deterministic)
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_parts; i += 128) acc += (double)dalpha_part[i];
+    dsum[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) dsum[threadIdx.x] += dsum[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) dalpha[0] = (accumulate ? dalpha[0] : 0.f) + (float)dsum[0];
   }
 }
 
