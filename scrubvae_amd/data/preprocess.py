@@ -39,8 +39,7 @@ def get_window_indices(ids, stride, window):
     return torch.from_numpy(np.ascontiguousarray(np.concatenate(out, axis=0)))
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = ops._stream
 
 
 def inv_kin_windows(pose, kinematic_tree, offset, direction_process="midfwd", want_offsets=True, want_root=True):

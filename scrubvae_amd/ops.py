@@ -23,7 +23,14 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream.  torch.cuda.current_stream() costs ~8 us per call (about 1 ms per
+    optimizer step over ~120 calls); the raw-handle query is ~20x cheaper."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
