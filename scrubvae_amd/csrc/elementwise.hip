@@ -413,18 +413,31 @@ __global__ __launch_bounds__(256) void colsum_batched_partial_kernel(const Colsu
   }
 }
 
-__global__ void colsum_batched_final_kernel(const ColsumTasks T, const float* __restrict__ part, int accumulate) {
-  const int gc = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gc >= T.col_begin[T.n]) return;
-  int t = 0;
-  while (t + 1 < T.n && gc >= T.col_begin[t + 1]) ++t;
-  const int c = gc - T.col_begin[t];
-  const int C = T.C[t];
-  const int chunks = (int)((T.rows[t] + CS_ROWS - 1) / CS_ROWS);
+// 256 threads = 8 columns x 32 chunk-lanes: lane s of a column sums chunks s, s+32, ... in fp64, the lane sums are
+// combined in lane order (deterministic)
+__global__ __launch_bounds__(256) void colsum_batched_final_kernel(const ColsumTasks T, const float* __restrict__ part, int accumulate) {
+  __shared__ double red[32][8];
+  const int cl = threadIdx.x & 7, sub = threadIdx.x >> 3;
+  const int gc = blockIdx.x * 8 + cl;
+  const bool ok = gc < T.col_begin[T.n];
+  int t = 0, c = 0, C = 1, chunks = 0;
+  if (ok) {
+    while (t + 1 < T.n && gc >= T.col_begin[t + 1]) ++t;
+    c = gc - T.col_begin[t];
+    C = T.C[t];
+    chunks = (int)((T.rows[t] + CS_ROWS - 1) / CS_ROWS);
+  }
   double s = 0.0;
-  for (int k = 0; k < chunks; ++k) s += (double)part[T.part_off[t] + (long long)k * C + c];
-  float* o = T.out[t];
-  o[c] = (accumulate ? o[c] : 0.f) + (float)s;
+  for (int k = sub; k < chunks; k += 32) s += (double)part[T.part_off[t] + (long long)k * C + c];
+  red[sub][cl] = s;
+  __syncthreads();
+  if (sub == 0 && ok) {
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) tot += red[i][cl];
+    float* o = T.out[t];
+    o[c] = (accumulate ? o[c] : 0.f) + (float)tot;
+  }
 }
 
 // ------------------------------------------------------------------------ latent heads
@@ -883,6 +896,6 @@ extern "C" int svae_colsum_batched(const svae_colsum_task* tasks, int n, void* w
   T.col_begin[n] = col;
   hipLaunchKernelGGL(colsum_batched_partial_kernel, dim3(blk), dim3(256), 0, ST(stream), T, (float*)ws);
   if (int e = check_launch("colsum_batched_partial")) return e;
-  hipLaunchKernelGGL(colsum_batched_final_kernel, dim3((col + 127) / 128), dim3(128), 0, ST(stream), T, (const float*)ws, accumulate);
+  hipLaunchKernelGGL(colsum_batched_final_kernel, dim3((col + 7) / 8), dim3(256), 0, ST(stream), T, (const float*)ws, accumulate);
   return check_launch("colsum_batched_final");
 }
