@@ -241,36 +241,52 @@ def train_epoch(config, model, loader, optimizer, scheduler, device="cuda", epoc
 
 
 def train(config, model, loader_dict, run=None):
-    """trainer.py:322-516 without the science-metric evaluation (sklearn decoders, clustering:
-    out of scope).  Keeps: optimizer/scheduler set-up, beta schedule, per-epoch
-    scrubber re-initialisation, weights every 5 epochs, optimizer state every 20."""
+    """trainer.py:322-516: optimizer / scheduler set-up, beta schedule, per-epoch scrubber re-initialisation, tuned
+    forgetting factors in the metrics, weights every 5 epochs, optimizer state every 20, `test_epoch` on
+    loader_dict["val"] from epoch 50 on.  The sklearn decodability / clustering metrics (trainer.py:414-507) are
+    outside the path.  Metrics go to `run.log(metrics, epoch)` when a W&B-like `run` is given and are
+    always appended as JSON lines to <out_path>/metrics.jsonl (the W&B-free log of SURVEY 8f N3)."""
+    import json
     optimizer, scheduler = get_optimizer_and_lr_scheduler(
         model, config["train"], config["model"].get("load_model"), config["model"].get("start_epoch"))
-    beta_scheduler = get_beta_schedule(config["loss"].get("prior"), config["train"].get("beta_anneal"))
+    beta_scheduler = (get_beta_schedule(config["loss"]["prior"], config["train"].get("beta_anneal"))
+                      if "prior" in config["loss"].keys() else None)
     start_epoch = config["model"].get("start_epoch") or 0
-    metrics = {}
+    out_path = config.get("out_path")
     for epoch in range(start_epoch + 1, config["train"]["num_epochs"] + 1):
         if beta_scheduler is not None:
             config["loss"]["prior"] = beta_scheduler.get(epoch)
+            print("Beta schedule: {:.3f}".format(config["loss"]["prior"]))
         t0 = time.time()
         train_metrics = train_epoch(config, model, loader_dict["train"], optimizer, scheduler, model.device, epoch)
         metrics = {"{}_train".format(k): v for k, v in train_metrics.items()}
-        metrics["time"] = time.time() - t0
         if "grad_reversal" in model.disentangle.keys():
             for k in model.disentangle["grad_reversal"].keys():
                 model.disentangle["grad_reversal"][k].reset_parameters()
-        if epoch % 5 == 0 and config.get("out_path"):
-            Path(config["out_path"] + "weights/").mkdir(parents=True, exist_ok=True)
-            torch.save({k: v.cpu() for k, v in model.state_dict().items()},
-                       "{}/weights/epoch_{}.pth".format(config["out_path"], epoch))
-            if epoch % 20 == 0:
-                Path(config["out_path"] + "checkpoints/").mkdir(parents=True, exist_ok=True)
-                ck = {"optimizer": optimizer.state_dict()}
-                if scheduler is not None:
-                    ck["lr_scheduler"] = scheduler.state_dict()
-                torch.save(ck, "{}/checkpoints/epoch_{}.pth".format(config["out_path"], epoch))
+        if "moving_avg_lsq" in model.disentangle.keys():  # automatically tuned smoothing factors (trainer.py:373-377)
+            for k in model.disentangle["moving_avg_lsq"].keys():
+                metrics["lambda_mals_{}".format(k)] = float(model.disentangle["moving_avg_lsq"][k].lam1.detach().cpu())
+        metrics["time"] = time.time() - t0
+        if epoch % 5 == 0:
+            if out_path:
+                print("Saving model to folder: {}".format(out_path))
+                Path(out_path + "weights/").mkdir(parents=True, exist_ok=True)
+                torch.save({k: v.cpu() for k, v in model.state_dict().items()}, "{}/weights/epoch_{}.pth".format(out_path, epoch))
+                if epoch % 20 == 0:
+                    Path(out_path + "checkpoints/").mkdir(parents=True, exist_ok=True)
+                    ck = {"optimizer": optimizer.state_dict()}
+                    if scheduler is not None:
+                        ck["lr_scheduler"] = scheduler.state_dict()
+                    torch.save(ck, "{}/checkpoints/epoch_{}.pth".format(out_path, epoch))
+            if epoch >= 50 and loader_dict.get("val") is not None:
+                test_metrics, _ = test_epoch(config, model, loader_dict["val"], model.device, epoch)
+                metrics.update({"{}_test".format(k): float(v) for k, v in test_metrics.items()})
         if run is not None:
             run.log(metrics, epoch)
+        if out_path:
+            Path(out_path).mkdir(parents=True, exist_ok=True)
+            with open(str(Path(out_path) / "metrics.jsonl"), "a") as f:
+                f.write(json.dumps({"epoch": epoch, **{k: float(v) for k, v in metrics.items()}}) + "\n")
     return model
 
 

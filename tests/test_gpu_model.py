@@ -414,3 +414,38 @@ def test_full_size_properties_b1024():
     for precision in ("bf16x6", "bf16x6w3"):                                              # (c)
         for k, v in losses["f32"].items():
             assert abs(losses[precision][k] - v) <= 1e-5 * abs(v), (precision, k, losses[precision][k], v)
+
+
+def test_train_loop_checkpoints_and_metrics_log(golden_dir, tmp_path):
+    """train() (trainer.py:322-516): epochs over a loader, weights every 5 epochs in the reference's state_dict format
+    (loadable with weights_only=True and accepted by a fresh model), the test epoch from epoch 50 on, and the JSON-lines
+    metrics log."""
+    import json
+    from scrubvae_amd.train.trainer import train
+    fx, cfg, loss_scale, opt, sd, data = load_fixture(golden_dir, "vanilla_tiny")
+    m, dis = build_model(cfg, sd)
+
+    class DS(torch.utils.data.Dataset):
+        kinematic_tree = cfg.kinematic_tree
+
+        def __len__(self):
+            return data["x6d"].shape[0]
+
+        def __getitem__(self, i):
+            return {k: v[i] for k, v in data.items()}
+
+    loader = torch.utils.data.DataLoader(DS(), batch_size=8, shuffle=False)
+    out = str(tmp_path) + "/"
+    config = {"train": {"optimizer": "adamw", "lr": 1e-4, "lr_schedule": "cawr", "num_epochs": 51, "beta_anneal": None},
+              "model": {"load_model": None, "start_epoch": 46}, "loss": dict(loss_scale), "disentangle": dis, "out_path": out,
+              "data": {"batch_size": 8}}
+    train(config, m, {"train": loader, "val": loader})
+    lines = [json.loads(l) for l in open(out + "metrics.jsonl")]
+    assert [l["epoch"] for l in lines] == [47, 48, 49, 50, 51]
+    assert all("total_train" in l and "time" in l for l in lines)
+    assert "total_test" in lines[3] and "total_test" not in lines[2]          # test epoch only at epoch 50 (>= 50 and % 5 == 0)
+    ck = torch.load(out + "weights/epoch_50.pth", map_location="cpu", weights_only=True)
+    assert set(ck) == set(sd)
+    m2, _ = build_model(cfg, ck)                                               # reference-format checkpoint loads strictly
+    back = m2.state_dict()
+    assert all(torch.equal(back[k].cpu(), v) for k, v in ck.items())
