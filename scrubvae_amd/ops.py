@@ -66,9 +66,9 @@ class LaunchTimer:
 
 TIMER = None  # set to a LaunchTimer to enable
 
-# First-use tile autotuning of the GEMM launches (fwd/dgrad/wgrad): each (geometry, kind) times
-# the four workgroup tiles once on scratch outputs and keeps the fastest.  Results do not
-# depend on the tile (same per-output summation order), so this is numerically inert.
+# First-use autotuning of the GEMM launches (fwd/dgrad/wgrad): each (geometry, kind) times every
+# candidate kernel variant / workgroup tile once on scratch outputs and keeps the fastest.  Within a
+# kernel family the result does not depend on the tile (same per-output summation order).
 AUTOTUNE = True
 AUTOTUNE_MIN_FLOPS = 2e8
 AUTOTUNE_REPS = 4
@@ -92,6 +92,7 @@ _KIND_ID = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 # "bf16": every fp32 operand is split into 3 / 2 / 1 bf16 pieces and the 6 / 3 / 1 leading cross
 # products run on the bf16 matrix cores with fp32 accumulation (csrc/gemm_bf16s.hip); bf16x6
 # is as accurate as f32.  Read when a Conv is constructed; convs below SPLIT_MIN_FLOPS stay f32.
+# The library default is "f32" (or $SVAE_PRECISION); bench.py selects "bf16x6w3".
 PRECISION = os.environ.get("SVAE_PRECISION", "f32")
 _PIECES = {"f32": 0, "bf16x6": 3, "bf16x6w3": 3, "bf16x3": 2, "bf16": 1}
 # "bf16x6w3": forward / data-gradient contractions with 3 pieces (6 products), WEIGHT-gradient contractions with 2
@@ -100,8 +101,9 @@ _PIECES = {"f32": 0, "bf16x6": 3, "bf16x6w3": 3, "bf16x3": 2, "bf16": 1}
 # (tests/studies/precision_bf16_split.py: worst gradient error vs fp64 identical to bf16x6, 3-7x below fp32's own).
 _WGRAD_PIECES = {"bf16x6w3": 2}
 SPLIT_MIN_FLOPS = float(os.environ.get("SVAE_SPLIT_MIN_FLOPS", 2e9))
-# VBBBNNN: V = 0: 4 waves, double-buffered LDS; 1: 4 waves, one LDS buffer; 2 / 3: 8 waves (BM = 128), one / two buffers
-# 4: wave-specialised (4 producer + 8 consumer waves); 5: wave-specialised 4 + 4
+# split gather kernels, code VBBBNNN: V = 0: 4 waves, double-buffered LDS; 1: 4 waves, one LDS buffer; 2 / 3: 8 waves
+# (BM = 128), one / two buffers; 4 / 5: wave-specialised (4 producer + 8 / 4 consumer waves), 2 tiles in flight;
+# 6 / 7: the same with 3 tiles in flight; 8: halo-image kernel (BM = 128)
 _SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2128064, 3128128, 3128064)
                        + (4128128, 4128064, 4064128) + tuple(5000000 + c for c in _TILES)
                        + (6128128, 6128064, 6064128) + tuple(7000000 + c for c in _TILES) + (8128128, 8128064))
