@@ -682,3 +682,93 @@ def mals_loss(st, yhat0, yhat1, y, delta=1e-4):
         st["lam1"] = torch.clamp(st["lam1"] + delta, 0.0, 1.0)
         st["lam0"] = st["lam1"] - st["lamdiff"]
     return (l0 + l1) * 0.5, st
+
+
+def maf_init(nx, n_classes, lamdiff=1e-2, dtype=torch.float32):
+    """MovingAverageFilter.__init__, disentangle.py:15-29."""
+    lam1 = torch.ones(n_classes, dtype=dtype) * 0.5
+    return {"m1": torch.zeros(n_classes, nx, dtype=dtype), "m2": torch.zeros(n_classes, nx, dtype=dtype), "lam1": lam1,
+            "lam2": lam1 + lamdiff, "lamdiff": lamdiff}
+
+
+def maf_loss(st, x, y, classes, delta=1e-3):
+    """disentangle.py:34-75: returns (loss, state with the forgetting factors moved); m1 / m2 themselves only change in
+    maf_update."""
+    st = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+    m1, m2 = torch.zeros_like(st["m1"]), torch.zeros_like(st["m2"])
+    for i, label in enumerate(classes):
+        xbar = torch.mean(x[(y == label).ravel(), :], dim=0)
+        d1, d2 = torch.linalg.norm(xbar - st["m1"][i]), torch.linalg.norm(xbar - st["m2"][i])
+        if d1 < d2:
+            st["lam1"][i] = torch.clamp(st["lam1"][i] - delta, 0.0, 1.0)
+            st["lam2"][i] = st["lam1"][i] + st["lamdiff"]
+        else:
+            st["lam2"][i] = torch.clamp(st["lam2"][i] + delta, 0.0, 1.0)
+            st["lam1"][i] = st["lam2"][i] - st["lamdiff"]
+        m1[i] = (1 - st["lam1"][i]) * xbar + st["lam1"][i] * st["m1"][i]
+        m2[i] = (1 - st["lam2"][i]) * xbar + st["lam2"][i] * st["m2"][i]
+    est = 0.5 * (m1 + m2)
+    d = torch.triu(est.T[..., None] - est.T[..., None, :], diagonal=1)
+    return torch.linalg.norm(d), st
+
+
+def maf_update(st, x, y, classes):
+    """disentangle.py:77-87."""
+    st = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+    for i, label in enumerate(classes):
+        xbar = torch.mean(x[(y == label).ravel(), :], dim=0)
+        st["m1"][i] = (1 - st["lam1"][i]) * xbar + st["lam1"][i] * st["m1"][i]
+        st["m2"][i] = (1 - st["lam2"][i]) * xbar + st["lam2"][i] * st["m2"][i]
+    return st
+
+
+def qda_init(nx, n_classes, lamdiff=1e-2, dtype=torch.float32):
+    """QuadraticDiscriminantFilter.__init__, disentangle.py:97-125."""
+    st = {"lamdiff": lamdiff}
+    for name in ("0a", "1a", "0b", "1b"):
+        st["m" + name] = torch.zeros(n_classes, nx, dtype=dtype)
+        st["S" + name] = torch.eye(nx, dtype=dtype)[None].repeat(n_classes, 1, 1)
+    st["lama"] = torch.ones(n_classes, dtype=dtype) * 0.2
+    st["lamb"] = st["lama"] + lamdiff
+    return st
+
+
+def _cgll(x, m, S):
+    """disentangle.py:130-135."""
+    resids = torch.sum((x - m) * torch.linalg.solve(S, (x - m).T).T, dim=1)
+    return -0.5 * (torch.logdet(S) + resids)
+
+
+def qda_update(st, x, y, classes):
+    """disentangle.py:137-165."""
+    st = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+    for i, label in enumerate(classes):
+        i0, i1 = (y != label).ravel(), (y == label).ravel()
+        x0m, x1m = torch.mean(x[i0], dim=0, keepdim=True), torch.mean(x[i1], dim=0, keepdim=True)
+        x0S, x1S = torch.cov(x[i0].T, correction=0), torch.cov(x[i1].T, correction=0)
+        for tag, lam in (("a", st["lama"][i]), ("b", st["lamb"][i])):
+            st["m0" + tag][i] = (1 - lam) * st["m0" + tag][i] + lam * x0m
+            st["m1" + tag][i] = (1 - lam) * st["m1" + tag][i] + lam * x1m
+            st["S0" + tag][i] = (1 - lam) * st["S0" + tag][i] + lam * x0S
+            st["S1" + tag][i] = (1 - lam) * st["S1" + tag][i] + lam * x1S
+    return st
+
+
+def qda_loss(st, x, y, classes, delta=1e-3, update=True):
+    """disentangle.py:167-232: returns (loss, state with the forgetting factors moved)."""
+    st = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+    ll_loss = 0
+    for i, label in enumerate(classes):
+        i0, i1 = (y != label).ravel(), (y == label).ravel()
+        lla0, lla1 = _cgll(x, st["m0a"][i: i + 1], st["S0a"][i]), _cgll(x, st["m1a"][i: i + 1], st["S1a"][i])
+        llb0, llb1 = _cgll(x, st["m0b"][i: i + 1], st["S0b"][i]), _cgll(x, st["m1b"][i: i + 1], st["S1b"][i])
+        lla, llb = torch.sum(i0 * lla0 + i1 * lla1), torch.sum(i0 * llb0 + i1 * llb1)
+        if update and (lla > llb):
+            st["lama"][i] = torch.clamp(st["lama"][i] - delta, 0.0, 1.0)
+            st["lamb"][i] = st["lama"][i] + st["lamdiff"]
+        elif update:
+            st["lamb"][i] = torch.clamp(st["lamb"][i] + delta, 0.0, 1.0)
+            st["lama"][i] = st["lamb"][i] - st["lamdiff"]
+        batch_y = (i1 * 2 - 1).to(x.dtype)
+        ll_loss = ll_loss + (batch_y @ (lla1 - lla0) + batch_y @ (llb1 - llb0)) * 0.5
+    return ll_loss / len(classes), st

@@ -9,7 +9,8 @@ FEAT_DIMS = {"avg_speed": 1, "part_speed": 4, "avg_speed_3d": 3, "heading": 2, "
 
 def model(model_config, load_model, epoch, disentangle_config, n_keypts, direction_process, loss_config=None,
           arena_size=None, kinematic_tree=None, bound=False, discrete_classes=None, device="cuda", verbose=1):
-    from scrubvae_amd.model.disentangle import GRScrubber, AdvNetScrubber, MovingAvgLeastSquares
+    from scrubvae_amd.model.disentangle import (AdvNetScrubber, GRScrubber, MovingAverageFilter, MovingAvgLeastSquares,
+                                                QuadraticDiscriminantFilter)
     from scrubvae_amd.model.residual import ResVAE
 
     feat_dim_dict = dict(FEAT_DIMS)
@@ -22,7 +23,7 @@ def model(model_config, load_model, epoch, disentangle_config, n_keypts, directi
         in_channels += 3
 
     methods = disentangle_config["method"] or {}
-    for unsupported in ("linear", "qda", "moving_avg", "direct_lsq"):
+    for unsupported in ("linear", "direct_lsq"):
         if unsupported in methods:
             raise NotImplementedError(
                 f"disentangle method '{unsupported}' is outside this build's scope (SURVEY.md 8a row A2 / 8f N4)")
@@ -46,6 +47,12 @@ def model(model_config, load_model, epoch, disentangle_config, n_keypts, directi
             feat: MovingAvgLeastSquares(model_config["z_dim"], feat_dim_dict[feat], bias=loss_config[feat + "_mals"] < 0,
                                         polynomial_order=disentangle_config["polynomial"], l2_reg=disentangle_config["l2_reg"])
             for feat in methods["moving_avg_lsq"]}
+
+    if "qda" in methods:  # get/model.py:86-94
+        disentangle["qda"] = {feat: QuadraticDiscriminantFilter(model_config["z_dim"], discrete_classes[feat]) for feat in methods["qda"]}
+    if "moving_avg" in methods:  # get/model.py:96-104
+        disentangle["moving_avg"] = {feat: MovingAverageFilter(model_config["z_dim"], discrete_classes[feat])
+                                     for feat in methods["moving_avg"]}
 
     if model_config["type"] != "rcnn":
         raise ValueError("only model.type == 'rcnn' exists (reference get/model.py:116)")

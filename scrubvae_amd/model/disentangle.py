@@ -204,3 +204,139 @@ class MovingAvgLeastSquares(nn.Module):
         self.lam0 = torch.where(down, lam0_dn, lam1_up - self.lamdiff)
         self.lam1 = torch.where(down, lam0_dn + self.lamdiff, lam1_up)
         return (l[0] + l[1]) * 0.5
+
+
+def _rank_sum(t, group):
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return True
+    return False
+
+
+class MovingAverageFilter(nn.Module):
+    """Streaming class-mean scrubber for a discrete variable (reference: disentangle.py:9-87; loss key `<feat>_ma`,
+    losses.py:286-289).  Two exponentially-forgetting estimates of every class mean of the latent; the loss is the
+    Frobenius norm of all pairwise differences of the class-mean estimates after folding in the current batch, and the
+    per-class forgetting factors move toward the estimate that was closer to the batch mean.  Stock torch device ops
+    (SURVEY 8a row A2); train.losses differentiates the [B, z] graph with torch.autograd and seeds the HIP backward.
+    Under data parallelism the class sums and counts are summed over the ranks (the gradient stays local)."""
+
+    def __init__(self, nx, classes, lamdiff=1e-2, delta=1e-3):
+        super().__init__()
+        self.classes = classes
+        k = len(classes)
+        self.register_buffer("m1", torch.zeros(k, nx))
+        self.register_buffer("m2", torch.zeros(k, nx))
+        self.register_buffer("lam1", torch.ones(k) * 0.5)
+        self.register_buffer("lam2", self.lam1 + lamdiff)
+        self.delta = delta
+        self.lamdiff = lamdiff
+        self.process_group = None
+
+    def forward(self, *args, **kwargs):
+        return None
+
+    def _class_means(self, x, y):
+        labels = torch.as_tensor(self.classes, device=x.device).reshape(1, -1)
+        onehot = (y.reshape(-1, 1).to(labels.dtype) == labels).to(x.dtype)  # [B, K]
+        sums, cnt = onehot.T @ x, onehot.sum(0)
+        g_sums, g_cnt = sums.detach().clone(), cnt.clone()
+        if _rank_sum(g_sums, self.process_group):
+            _rank_sum(g_cnt, self.process_group)
+            sums, cnt = sums + (g_sums - sums.detach()), g_cnt
+        return sums / cnt[:, None]
+
+    def evaluate_loss(self, x, y):
+        xbar = self._class_means(x, y)
+        with torch.no_grad():
+            down = torch.linalg.norm(xbar - self.m1, dim=1) < torch.linalg.norm(xbar - self.m2, dim=1)
+            lam1_dn = torch.clamp(self.lam1 - self.delta, 0.0, 1.0)
+            lam2_up = torch.clamp(self.lam2 + self.delta, 0.0, 1.0)
+            self.lam1 = torch.where(down, lam1_dn, lam2_up - self.lamdiff)
+            self.lam2 = torch.where(down, lam1_dn + self.lamdiff, lam2_up)
+        m1 = (1 - self.lam1)[:, None] * xbar + self.lam1[:, None] * self.m1
+        m2 = (1 - self.lam2)[:, None] * xbar + self.lam2[:, None] * self.m2
+        est = 0.5 * (m1 + m2)
+        d = torch.triu(est.T[..., None] - est.T[..., None, :], diagonal=1)
+        return torch.linalg.norm(d)
+
+    def update(self, x, y):
+        with torch.no_grad():
+            xbar = self._class_means(x, y)
+            self.m1 = (1 - self.lam1)[:, None] * xbar + self.lam1[:, None] * self.m1
+            self.m2 = (1 - self.lam2)[:, None] * xbar + self.lam2[:, None] * self.m2
+        return self
+
+
+class QuadraticDiscriminantFilter(nn.Module):
+    """Two streaming one-vs-rest quadratic discriminants per class with automatically tuned forgetting factors
+    (reference: disentangle.py:90-232; loss key `<feat>_qda`, losses.py:248-252).  Stock torch device ops behind the
+    reference API (SURVEY 8a row A2).  Single-rank statistics use torch.mean / torch.cov exactly as the reference;
+    under data parallelism the member / non-member moments are summed over the ranks."""
+
+    def __init__(self, nx, classes, lamdiff=1e-2, delta=1e-3):
+        super().__init__()
+        self.classes = classes
+        k = len(classes)
+        for name in ("0a", "1a", "0b", "1b"):
+            self.register_buffer("m" + name, torch.zeros(k, nx))
+            self.register_buffer("S" + name, torch.eye(nx)[None, :].repeat(k, 1, 1))
+        self.register_buffer("lama", torch.ones(k) * 0.2)
+        self.register_buffer("lamb", self.lama + lamdiff)
+        self.delta = delta
+        self.lamdiff = lamdiff
+        self.process_group = None
+
+    def forward(self, *args, **kwargs):
+        return None
+
+    @staticmethod
+    def cgll(x, m, S):
+        r = x - m
+        resids = torch.sum(r * torch.linalg.solve(S, r.T).T, dim=1)
+        return -0.5 * (torch.logdet(S) + resids)
+
+    def _moments(self, x, mask):
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            w = mask.to(x.dtype)[:, None]
+            stats = torch.cat([(w * x).sum(0), ((w * x).T @ x).reshape(-1), w.sum().reshape(1)])
+            _rank_sum(stats, self.process_group)
+            nx, n = x.shape[1], stats[-1]
+            mean = stats[:nx] / n
+            return mean[None], stats[nx:-1].reshape(nx, nx) / n - mean[:, None] * mean[None, :]
+        xs = x[mask]
+        return torch.mean(xs, dim=0, keepdim=True), torch.cov(xs.T, correction=0)
+
+    def update(self, x, y):
+        with torch.no_grad():
+            for i, label in enumerate(self.classes):
+                i1 = (y == label).ravel()
+                x0m, x0S = self._moments(x, ~i1)
+                x1m, x1S = self._moments(x, i1)
+                for tag, lam in (("a", self.lama[i]), ("b", self.lamb[i])):
+                    for cls, (xm, xS) in (("0", (x0m, x0S)), ("1", (x1m, x1S))):
+                        getattr(self, "m" + cls + tag)[i] = (1 - lam) * getattr(self, "m" + cls + tag)[i] + lam * xm
+                        getattr(self, "S" + cls + tag)[i] = (1 - lam) * getattr(self, "S" + cls + tag)[i] + lam * xS
+        return self
+
+    def evaluate_loss(self, x, y, update=True):
+        ll_loss = 0
+        for i, label in enumerate(self.classes):
+            i1 = (y == label).ravel()
+            i0 = ~i1
+            lla0, lla1 = self.cgll(x, self.m0a[i: i + 1], self.S0a[i]), self.cgll(x, self.m1a[i: i + 1], self.S1a[i])
+            llb0, llb1 = self.cgll(x, self.m0b[i: i + 1], self.S0b[i]), self.cgll(x, self.m1b[i: i + 1], self.S1b[i])
+            if update:
+                with torch.no_grad():
+                    ll = torch.stack([torch.sum(i0 * lla0 + i1 * lla1), torch.sum(i0 * llb0 + i1 * llb1)])
+                    _rank_sum(ll, self.process_group)
+                    a_better = ll[0] > ll[1]
+                    lama_dn = torch.clamp(self.lama[i] - self.delta, 0.0, 1.0)
+                    lamb_up = torch.clamp(self.lamb[i] + self.delta, 0.0, 1.0)
+                    self.lama[i] = torch.where(a_better, lama_dn, lamb_up - self.lamdiff)
+                    self.lamb[i] = torch.where(a_better, lama_dn + self.lamdiff, lamb_up)
+            batch_y = (i1 * 2 - 1).to(x.dtype)
+            ll_loss = ll_loss + (batch_y @ (lla1 - lla0) + batch_y @ (llb1 - llb0)) * 0.5
+        return ll_loss / len(self.classes)

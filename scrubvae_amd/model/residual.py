@@ -659,6 +659,8 @@ class ResVAE(nn.Module):
                     data_o["disentangle"][method][k] = [torch.softmax(o[:, :2], -1) for o in outs]
                 elif method == "moving_avg_lsq":
                     data_o["disentangle"][method][k] = m(mu[:, : self.z_dim])
+                elif method in ("moving_avg", "qda"):  # stateful filters: forward() is a no-op (disentangle.py:31-32,127-128)
+                    data_o["disentangle"][method][k] = m(mu[:, : self.z_dim])
                 else:
                     raise NotImplementedError(f"scrubber '{method}' is outside this build's scope (SURVEY 8a row A2)")
         self._state = dict(B=B, flat=flat, h=h, eps=eps, mu=mu, sigma=sigma, zc=zc, klp=klp, data=data)

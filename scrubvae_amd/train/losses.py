@@ -41,7 +41,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     Bg = B * world  # losses are normalised by the GLOBAL batch so that summed grads match 1 GPU
     train = model.training and torch.is_grad_enabled()
     for k in loss_scale.keys():
-        if k in SUPPORTED or k.endswith("_gr") or k.endswith("_an") or k.endswith("_mals"):
+        if k in SUPPORTED or k.endswith(("_gr", "_an", "_mals", "_ma", "_qda")):
             continue
         raise NotImplementedError(f"loss '{k}' is outside this build's scope (SURVEY 8a: L5/A2 rows)")
     batch_loss = {}
@@ -183,6 +183,23 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                         W0, W1 = m._W
                         zin = m.nx_in
                         d_mu[:, :zin] += (float(loss_scale[lk]) / Bg) * ((y0 - tgt) @ W0[:zin].T + (y1 - tgt) @ W1[:zin].T)
+            elif method in ("moving_avg", "qda"):  # losses.py:248-252,286-289
+                m = model.disentangle[method][key]
+                lk = key + ("_ma" if method == "moving_avg" else "_qda")
+                sc = float(loss_scale.get(lk, 0.0))
+                mu_t = st["mu"][:, :z].detach().clone().requires_grad_(bool(train and sc != 0))
+                tgt = data[key].to(model.device)
+                with torch.enable_grad():
+                    val = m.evaluate_loss(mu_t, tgt)
+                    if method == "qda":
+                        val = val / Bg
+                v = _scalar(model, lk)
+                v.copy_(val.detach().reshape(1))
+                batch_loss[lk] = v.view(()).clone()
+                if lk in loss_scale:
+                    add_total(lk, v)
+                    if train and sc != 0:  # seed of the HIP backward: d(scale * loss) / d mu through the small torch graph
+                        d_mu[:, :z] += sc * torch.autograd.grad(val, mu_t)[0]
             else:
                 raise NotImplementedError(f"scrubber '{method}' is outside this build's scope (SURVEY 8a row A2)")
 

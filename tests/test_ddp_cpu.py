@@ -163,3 +163,54 @@ def test_gloo_world2_streaming_scrubber_matches_one_rank():
     for r in range(2):
         for k, v in ref.state_dict().items():
             assert torch.allclose(torch.from_numpy(res[r][k]), v, rtol=1e-5, atol=1e-6), (r, k)
+
+
+def _filter_worker(rank, world, port, q, which):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    parallel.init_distributed(backend="gloo")
+    try:
+        from scrubvae_amd.model import disentangle as D
+        g = torch.Generator().manual_seed(2)
+        x = torch.randn(32, 6, generator=g)
+        y = (torch.arange(32) % 4).reshape(-1, 1)
+        lo, hi = parallel.shard_range(32, rank, world)
+        m = getattr(D, which)(6, torch.arange(4))
+        tot = 0.0
+        for _ in range(3):
+            xl = x[lo:hi].clone().requires_grad_(True)
+            val = m.evaluate_loss(xl, y[lo:hi])
+            tot = float(val.detach())
+            m.update(x[lo:hi], y[lo:hi])
+        q.put((rank, tot, {k: v.numpy() for k, v in m.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["MovingAverageFilter", "QuadraticDiscriminantFilter"])
+def test_gloo_world2_class_filters_match_one_rank(which):
+    """Class sums / counts (moving average) and member / non-member moments (QDA) are summed over the ranks: 2 ranks with
+    half batches end with the buffers of 1 rank with the batch; the QDA loss is a sum over samples, so the rank values add up."""
+    from scrubvae_amd.model import disentangle as D
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(32, 6, generator=g)
+    y = (torch.arange(32) % 4).reshape(-1, 1)
+    ref = getattr(D, which)(6, torch.arange(4))
+    for _ in range(3):
+        want = float(ref.evaluate_loss(x.clone().requires_grad_(True), y).detach())
+        ref.update(x, y)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_filter_worker, args=(r, 2, port, q, which)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (t, sd) for r, t, sd in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        for k, v in ref.state_dict().items():
+            assert torch.allclose(torch.from_numpy(res[r][1][k]), v, rtol=2e-4, atol=1e-5), (r, k)
+    got = res[0][0] if which == "MovingAverageFilter" else res[0][0] + res[1][0]
+    assert abs(got - want) <= 2e-4 * abs(want) + 1e-5
