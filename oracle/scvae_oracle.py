@@ -772,3 +772,11 @@ def qda_loss(st, x, y, classes, delta=1e-3, update=True):
         batch_y = (i1 * 2 - 1).to(x.dtype)
         ll_loss = ll_loss + (batch_y @ (lla1 - lla0) + batch_y @ (llb1 - llb0)) * 0.5
     return ll_loss / len(classes), st
+
+
+def direct_lsq_loss(zmat, y, bias=False):
+    """losses.py:173-179."""
+    if bias:
+        zmat = torch.column_stack((zmat, torch.ones(zmat.shape[0], 1, dtype=zmat.dtype)))
+    yhat = zmat @ torch.linalg.solve(zmat.T @ zmat, zmat.T @ y)
+    return ((yhat - y) ** 2).sum()

@@ -23,7 +23,7 @@ def model(model_config, load_model, epoch, disentangle_config, n_keypts, directi
         in_channels += 3
 
     methods = disentangle_config["method"] or {}
-    for unsupported in ("linear", "direct_lsq"):
+    for unsupported in ("linear",):
         if unsupported in methods:
             raise NotImplementedError(
                 f"disentangle method '{unsupported}' is outside this build's scope (SURVEY.md 8a row A2 / 8f N4)")

@@ -41,7 +41,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     Bg = B * world  # losses are normalised by the GLOBAL batch so that summed grads match 1 GPU
     train = model.training and torch.is_grad_enabled()
     for k in loss_scale.keys():
-        if k in SUPPORTED or k.endswith(("_gr", "_an", "_mals", "_ma", "_qda")):
+        if k in SUPPORTED or k.endswith(("_gr", "_an", "_mals", "_ma", "_qda", "_lsq")):
             continue
         raise NotImplementedError(f"loss '{k}' is outside this build's scope (SURVEY 8a: L5/A2 rows)")
     batch_loss = {}
@@ -183,6 +183,27 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                         W0, W1 = m._W
                         zin = m.nx_in
                         d_mu[:, :zin] += (float(loss_scale[lk]) / Bg) * ((y0 - tgt) @ W0[:zin].T + (y1 - tgt) @ W1[:zin].T)
+            elif method == "direct_lsq":  # direct_lsq_loss, losses.py:173-179,254-257: stateless least-squares decoder
+                lk = key + "_lsq"
+                sc = float(loss_scale[lk])
+                zm = st["mu"][:, :z]
+                if sc < 0:  # bias column
+                    zm = torch.column_stack((zm, torch.ones(B, 1, device=zm.device)))
+                tgt = model._prep(data[key])
+                zz, zy = zm.T @ zm, zm.T @ tgt
+                if world > 1:  # normal equations of the GLOBAL batch
+                    model._allreduce(zz)
+                    model._allreduce(zy)
+                Wd = torch.linalg.solve(zz, zy)
+                res = zm @ Wd - tgt
+                v = _scalar(model, lk)
+                v.copy_((res * res).sum().reshape(1))
+                batch_loss[lk] = v.view(()).clone()
+                add_total(lk, v)
+                if train and sc != 0:
+                    # d/d mu of the summed squared residual: the decoder is the minimiser, so its own dependence on mu
+                    # contributes nothing (dL/dW = 0) and the gradient is 2 * res * W^T
+                    d_mu[:, :z] += (2.0 * sc) * (res @ Wd[:z].T)
             elif method in ("moving_avg", "qda"):  # losses.py:248-252,286-289
                 m = model.disentangle[method][key]
                 lk = key + ("_ma" if method == "moving_avg" else "_qda")

@@ -78,7 +78,50 @@ def run(method, refs):
     print(f"saved {path} {os.path.getsize(path)/1e6:.2f} MB", {k: round(float(v), 5) for k, v in bl.items()})
 
 
+def run_lsq(refs):
+    """direct_lsq (stateless least-squares decoder loss, losses.py:173-179): one step, losses + encoder-head gradient."""
+    get_model, get_batch_loss, predict_batch = refs
+    arena = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    feats = ["avg_speed_3d", "heading"]
+    cfg = O.OracleConfig(diag=True, method={"direct_lsq": feats}, features=feats, n_keypts=18, window=64, z_dim=8, kernel=5,
+                         channel=(8, 8, 16, 16, 32), arena_size=arena)
+    B, name = 16, "lsq_tiny"
+    loss = {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_lsq": 0.4, "heading_lsq": 0.25}
+    sd = O.init_state_dict(cfg, seed=len(name))
+    data = O.synth_batch(cfg, B, seed=len(name))
+    eps = torch.randn(B, cfg.z_dim, generator=torch.Generator().manual_seed(7))
+    model_config = dict(type="rcnn", kernel=cfg.kernel, z_dim=cfg.z_dim, window=cfg.window, activation="prelu", diag=True,
+                        init_dilation=None, prior="gaussian", channel=list(cfg.channel))
+    dis_config = dict(method=cfg.method, alpha=1.0, features=feats)
+    model = get_model(model_config, None, None, dis_config, cfg.n_keypts, "midfwd", loss_config=loss, arena_size=arena,
+                      kinematic_tree=cfg.kinematic_tree, bound=False, discrete_classes=None, device="cpu", verbose=0)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    model.train()
+    with MF.Patch(eps, torch.arange(B)):
+        data_o = predict_batch(model, data, model.disentangle_keys)
+        bl = get_batch_loss(model, data, data_o, loss, dis_config)
+    bl["total"].backward()
+    fx = {"eps/0": eps.numpy(), "s0/mu": data_o["mu"].detach().numpy()}
+    for k, v in data.items():
+        fx["in/" + k] = v.numpy()
+    for k, v in sd.items():
+        fx["sd/" + k] = v.numpy()
+    for k, v in bl.items():
+        fx["s0/loss/" + k] = v.detach().numpy()
+    for n, p in model.named_parameters():
+        if p.grad is not None and n.startswith("encoder.fc_mu"):
+            fx["s0/grad/" + n] = p.grad.numpy().copy()
+    for k in feats:
+        print("  oracle direct_lsq", k, float(O.direct_lsq_loss(data_o["mu"].detach(), data[k])), float(bl[k + "_lsq"]))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"saved {path} {os.path.getsize(path)/1e6:.2f} MB", {k: round(float(v), 5) for k, v in bl.items()})
+
+
 if __name__ == "__main__":
     refs = MF.import_reference()
-    for method in ("moving_avg", "qda"):
-        run(method, refs)
+    if "--lsq-only" not in sys.argv:
+        for method in ("moving_avg", "qda"):
+            run(method, refs)
+    run_lsq(refs)

@@ -87,3 +87,43 @@ def test_hip_model_with_classfilter_matches_reference(golden_dir, method):
         s = m.disentangle[method]["ids"]
         for b in bufs:
             assert rel(getattr(s, b).cpu(), fx[f"s{step}/{b}"]) < (1e-4 if step == 0 else 1e-2), (step, b)
+
+
+# ------------------------------------------------------------------ direct_lsq (stateless least-squares decoder loss)
+LSQ_FEATS = ["avg_speed_3d", "heading"]
+LSQ_LOSS = {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_lsq": 0.4, "heading_lsq": 0.25}
+
+
+def test_oracle_direct_lsq_matches_reference(golden_dir):
+    fx, sd, data = load(golden_dir, "lsq_tiny")
+    mu = torch.from_numpy(fx["s0/mu"])
+    for k in LSQ_FEATS:
+        assert rel(O.direct_lsq_loss(mu, data[k]), fx[f"s0/loss/{k}_lsq"]) < 1e-5, k
+
+
+@pytest.mark.gpu
+def test_hip_model_with_direct_lsq_matches_reference(golden_dir):
+    """losses and the encoder-head gradient (which carries the 2 * res * W^T seed) vs one step of the real reference."""
+    from scrubvae_amd.get import model as get_model
+    from scrubvae_amd.train.losses import get_batch_loss
+    fx, sd, data = load(golden_dir, "lsq_tiny")
+    cfg = O.OracleConfig(diag=True, method={"direct_lsq": LSQ_FEATS}, features=LSQ_FEATS, n_keypts=18, window=64, z_dim=8, kernel=5,
+                         channel=(8, 8, 16, 16, 32), arena_size=ARENA)
+    mc = dict(type="rcnn", kernel=cfg.kernel, z_dim=cfg.z_dim, window=cfg.window, activation="prelu", diag=True, init_dilation=None,
+              prior="gaussian", channel=list(cfg.channel))
+    dis = dict(method=cfg.method, alpha=1.0, features=LSQ_FEATS)
+    m = get_model(mc, None, None, dis, cfg.n_keypts, "midfwd", loss_config=LSQ_LOSS, arena_size=ARENA, kinematic_tree=cfg.kinematic_tree,
+                  device="cuda", verbose=0)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    m.train()
+    batch = {k: v.cuda() for k, v in data.items()}
+    batch["eps"] = torch.from_numpy(fx["eps/0"]).cuda()
+    bl = get_batch_loss(m, batch, m(batch), LSQ_LOSS, dis)
+    for k in fx.files:
+        if k.startswith("s0/loss/"):
+            assert rel(bl[k.split("/")[-1]].detach().cpu(), fx[k]) < 1e-4, k
+    bl["total"].backward()
+    g = m.grads_state_dict()
+    for n in ("encoder.fc_mu.weight", "encoder.fc_mu.bias"):
+        assert rel(g[n].cpu(), torch.from_numpy(fx["s0/grad/" + n])) < 2e-3, n
