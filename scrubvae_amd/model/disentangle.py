@@ -177,9 +177,7 @@ class MovingAvgLeastSquares(nn.Module):
         return [x @ W0, x @ W1]
 
     def _allreduce(self, t):
-        import torch.distributed as dist
-        if dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+        _rank_sum(t, self.process_group)
         return t
 
     def update(self, x, y):
@@ -207,9 +205,15 @@ class MovingAvgLeastSquares(nn.Module):
 
 
 def _rank_sum(t, group):
+    """In-place SUM over the data-parallel ranks; False when there is a single rank."""
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if t.is_cuda and dist.get_backend(group) == "gloo":  # test configuration (ranks sharing one GPU): stage through the host
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return True
     return False
 
