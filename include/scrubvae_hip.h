@@ -41,7 +41,7 @@ typedef enum {
   SVAE_ERR_ARG = -5        /* null pointer / bad enum */
 } svae_status;
 
-#define SVAE_MAX_TAPS 32
+#define SVAE_MAX_TAPS 128
 #define SVAE_MAX_JOINTS 32
 #define SVAE_MAX_CHAINS 8
 #define SVAE_MAX_CHAIN_LEN 8

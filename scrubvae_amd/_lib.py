@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVAE_LIB_PATH") or os.path.join(_HERE, "csrc", "libscrubvae_hip.so")  # env: kernel experiments only
 
-MAX_TAPS, MAX_JOINTS, MAX_CHAINS, MAX_CHAIN_LEN = 32, 32, 8, 8
+MAX_TAPS, MAX_JOINTS, MAX_CHAINS, MAX_CHAIN_LEN = 128, 32, 8, 8
 
 
 class ConvDesc(C.Structure):

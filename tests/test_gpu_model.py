@@ -39,7 +39,8 @@ def to_dev(data):
     return {k: v.cuda() for k, v in data.items()}
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "rotation_tiny", "fullL_ids_tiny", "tc_tiny", "vanilla_default_B4"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "rotation_tiny", "fullL_ids_tiny", "tc_tiny", "vanilla_default_B4",
+                                  "w256_tiny", "w256_6blocks_tiny"])
 def test_step0_matches_reference_fixture(golden_dir, name):
     from scrubvae_amd.train.losses import get_batch_loss
     fx, cfg, loss_scale, opt, sd, data = load_fixture(golden_dir, name)
@@ -188,6 +189,45 @@ def test_oracle_parity_seeded_j23():
     for n, g in g_o.items():
         dd = float((grads[n] - g).abs().max()) / (float(g.abs().max()) + 1e-3 * gmax)
         assert dd < 2e-2, (n, dd)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x6w3"])
+def test_oracle_parity_config5_wide_w256(precision):
+    """BASELINE configs[4] at its full widths (window 256, six residual blocks, channels 64..4096, 23 joints; 293 M
+    parameters), B=4 so that the CPU oracle finishes in seconds: HIP vs oracle on seeded inputs.  The reference cannot
+    construct six blocks (see tests/golden/make_fixtures.py); its arithmetic at this depth is pinned by the
+    `w256_6blocks_tiny` fixture above."""
+    from scrubvae_amd import ops
+    from scrubvae_amd.train.losses import get_batch_loss
+    cfg = O.OracleConfig(n_keypts=23, window=256, z_dim=32, kernel=5, diag=True, arena_size=ARENA,
+                         channel=(64, 128, 256, 512, 1024, 2048, 4096), kinematic_tree=O.skeleton_tree(23))
+    sd = O.init_state_dict(cfg, seed=13)
+    data = O.synth_batch(cfg, 4, seed=4)
+    eps = torch.randn(4, 32, generator=torch.Generator().manual_seed(6))
+    ls = {"jpe": 1.0, "root": 1.0, "prior": 1.0}
+    bl_o, g_o, _, out_o = O.train_step(sd, cfg, data, ls, eps)
+    prev = ops.PRECISION
+    ops.set_precision(precision)
+    try:
+        model, dis = build_model(cfg, sd)
+        model.train()
+        d = to_dev(data)
+        d["eps"] = eps.cuda()
+        data_o = model(d)
+        bl = get_batch_loss(model, d, data_o, ls, dis)
+        bl["total"].backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(prev)
+    for k in ("mu", "z", "x6d", "root"):
+        assert rel(data_o[k].cpu(), out_o[k].detach()) < 5e-5, k
+    for k in bl_o:
+        assert rel(bl[k].detach().cpu(), bl_o[k]) < 1e-4, k
+    grads = {k: v.cpu() for k, v in model.grads_state_dict().items()}
+    gmax = max(float(g.abs().max()) for g in g_o.values())
+    for n, g in g_o.items():
+        dd = float((grads[n] - g).abs().max()) / (float(g.abs().max()) + 1e-3 * gmax)
+        assert dd < 5e-2, (n, dd)
 
 
 def test_reference_style_loop_with_torch_optimizer():
@@ -350,7 +390,7 @@ def bf16x6_everywhere(request):
     ops.SPLIT_MIN_FLOPS = keep[1]
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "fullL_ids_tiny", "vanilla_default_B4"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "fullL_ids_tiny", "vanilla_default_B4", "w256_6blocks_tiny"])
 def test_step0_matches_reference_fixture_bf16x6(golden_dir, name, bf16x6_everywhere):
     """The reference fixtures at the SAME fp32 tolerances with the contractions on the bf16 matrix cores
     (bench.py's default precision): the 3-piece split is fp32-accurate, not a reduced-precision mode."""
