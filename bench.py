@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="windows per GPU")
     ap.add_argument("--joints", type=int, default=23)
     ap.add_argument("--window", type=int, default=64)
+    ap.add_argument("--channels", default=",".join(map(str, CHANNELS)),
+                    help="model.channel, comma separated; 'wide6' = configs[4]'s six blocks 64..4096 (use with --window 256)")
     ap.add_argument("--full", action="store_true", help="configs[2]: conditional + grad-reversal + adversarial heads")
     ap.add_argument("--local-bn", action="store_true", help="per-rank BatchNorm statistics (no sync-BN collectives)")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph (single GPU)")
@@ -56,10 +58,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--timer-kinds", default="fwd,dgrad", help="GEMM kinds bracketed with HIP events (fwd,dgrad,wgrad)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.channel_list = WIDE6 if args.channels == "wide6" else [int(c) for c in args.channels.split(",")]
+    return args
 
 
 CHANNELS = [64, 128, 256, 512, 1024]
+WIDE6 = [64, 128, 256, 512, 1024, 2048, 4096]
 ARENA = [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]
 
 
@@ -76,7 +81,7 @@ def make_cfg(args):
 def build_model(args, method, feats, tree):
     from scrubvae_amd.get import model as get_model
     mc = dict(type="rcnn", kernel=5, z_dim=32, window=args.window, activation="prelu", diag=True,
-              init_dilation=None, prior="gaussian", channel=CHANNELS)
+              init_dilation=None, prior="gaussian", channel=args.channel_list)
     dis = dict(method=method, alpha=1.0, features=feats)
     torch.manual_seed(0)
     m = get_model(mc, None, None, dis, args.joints, "midfwd", arena_size=torch.tensor(ARENA), kinematic_tree=tree,
@@ -88,7 +93,13 @@ def cpu_baseline(args, method, feats, loss, sample_b=128, steps=50):
     """cpu_baseline leg: the CPU oracle's train_step (the only place bench.py touches oracle/)
     on a bounded sample (sample_b windows) of the same workload."""
     from oracle import scvae_oracle as O
-    cfg = O.OracleConfig(n_keypts=args.joints, window=args.window, z_dim=32, kernel=5, diag=True,
+    # keep the sample at ~10-30 s of CPU work whatever the model size (default model: 0.76 GFLOP/window/step)
+    def cost(ch, w):
+        return sum(a * b * (w >> (i + 1)) for i, (a, b) in enumerate(zip(ch, ch[1:])))
+    work = cost(args.channel_list, args.window) / cost(CHANNELS, 64)
+    if work > 1.5:
+        sample_b, steps = max(4, int(128 / work) // 4 * 4), max(2, int(50 / work))
+    cfg = O.OracleConfig(n_keypts=args.joints, window=args.window, z_dim=32, kernel=5, diag=True, channel=tuple(args.channel_list),
                          arena_size=torch.tensor(ARENA), kinematic_tree=O.skeleton_tree(args.joints), method=method,
                          features=feats, discrete_classes={"ids": torch.arange(4)} if args.full else None)
     torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))  # the box's CPU share
@@ -114,7 +125,7 @@ def elbo_check(args, cfg, sd, data, eps, perm, loss, method, feats, oracle_losse
     from scrubvae_amd.get import model as get_model
     from scrubvae_amd.train.losses import get_batch_loss
     mc = dict(type="rcnn", kernel=5, z_dim=32, window=args.window, activation="prelu", diag=True, init_dilation=None,
-              prior="gaussian", channel=CHANNELS)
+              prior="gaussian", channel=args.channel_list)
     dis = dict(method=method, alpha=1.0, features=feats)
     m = get_model(mc, None, None, dis, args.joints, "midfwd", arena_size=torch.tensor(ARENA), kinematic_tree=cfg.kinematic_tree,
                   discrete_classes=cfg.discrete_classes, device="cuda", verbose=0)
@@ -234,15 +245,16 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         out = {
-            "metric": "pose-windows/sec (ELBO-match) on synthetic 64-frame mouse skeletons",
+            "metric": f"pose-windows/sec (ELBO-match) on synthetic {args.window}-frame mouse skeletons",
             "value": round(B * world * args.steps / dt, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else f"f32 ({args.precision} split on the bf16 matrix cores)",
             "data": "synthetic",
             "config": {"workload": ("configs[2] full SC-VAE (conditional + grad_reversal x2 + adversarial_net)" if args.full else
+                                    "configs[4] wide six-block rcnn, recon+KL (jpe+root+prior), AdamW" if args.channel_list == WIDE6 else
                                     "configs[1] mouse-skeleton rcnn, recon+KL (jpe+root+prior), AdamW") +
-                                   f", batch {B}/GPU, window {args.window}, {args.joints} joints, z=32, channels [64,128,256,512,1024]",
+                                   f", batch {B}/GPU, window {args.window}, {args.joints} joints, z=32, channels [{','.join(map(str, args.channel_list))}]",
                        "batch_per_gpu": B, "global_batch": B * world, "window": args.window, "joints": args.joints,
                        "launch": "hipGraph replay" if args.graph else "eager launches",
                        "streams": "serialised" if args.serial_streams else "3 HIP streams (weight gradients / skip branches overlap the main chain)",
@@ -269,7 +281,10 @@ def main():
                                                "on 3 streams, where a launch's duration is not the kernel's own time); "
                                                "profiles/*serial* is the rocprofv3 summary of `bench.py --serial-streams`",
                                    "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                                   "frac": round(tf / peak, 4), "traffic": pmc_traffic("svae::" + kname),
+                                   "frac": round(tf / peak, 4),
+                                   # the committed PMC passes are of the default command (configs[1], batch 1024)
+                                   "traffic": pmc_traffic("svae::" + kname) if (args.channel_list == CHANNELS and args.window == 64 and B == 1024
+                                                                                and not args.full) else None,
                                    "peak_note": (f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {PRODUCTS[args.precision]} "
                                                  "matrix-core products per algorithmic multiply (achieved counts algorithmic FLOPs)"
                                                  if split_kernel else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
