@@ -780,3 +780,32 @@ def direct_lsq_loss(zmat, y, bias=False):
         zmat = torch.column_stack((zmat, torch.ones(zmat.shape[0], 1, dtype=zmat.dtype)))
     yhat = zmat @ torch.linalg.solve(zmat.T @ zmat, zmat.T @ y)
     return ((yhat - y) ** 2).sum()
+
+
+def mcmi_value(x_s, y_s, var_s, bandwidth, x, y):
+    """MutInfoEstimator (disentangle.py:234-317) as one numpy float64 expression.  x_s [S, dx], y_s [S, dy]: mixture
+    centres; var_s: [1] ("sphere", = bandwidth) or [S, dx] ("diagonal", = diag(L_s)^2 + bandwidth); x [B, dx], y [B, dy].
+    Returns mean_b[lse_s log N(x_b,y_b | s) - lse_s log N(x_b | s) - lse_s log N(y_b | s)] with the reference's
+    normalisation: log A_x = dx*(log 2pi + log var) (sphere) or dx*log 2pi + sum log var_s (diagonal), log A_y =
+    dy*(log 2pi + log gamma), each density = -0.5*(log A + squared distance); log-sum-exp, not log-mean-exp
+    (disentangle.py:297-317)."""
+    import numpy as np
+    from scipy.special import logsumexp
+    x_s, y_s, var_s, x, y = (np.asarray(a, dtype=np.float64) for a in (x_s, y_s, var_s, x, y))
+    dx, dy = x_s.shape[1], y_s.shape[1]
+    log2pi = np.log(2 * np.pi)
+    if var_s.ndim == 1:
+        logA_x = np.full((1, 1), dx * (log2pi + np.log(var_s[0])))
+        var = var_s[0]
+    else:
+        logA_x = (dx * log2pi + np.log(var_s).sum(-1))[None, :]
+        var = var_s[None, :, :]
+    logA_y = dy * (log2pi + np.log(bandwidth))
+    ex = x[:, None, :] - x_s[None, :, :]
+    ey = y[:, None, :] - y_s[None, :, :]
+    sdx = (ex * ex / var).sum(-1)
+    sdy = (ey * ey / bandwidth).sum(-1)
+    pxy = logsumexp(-0.5 * (logA_x + logA_y + sdx + sdy), axis=-1)
+    px = logsumexp(-0.5 * (logA_x + sdx), axis=-1)
+    py = logsumexp(-0.5 * (logA_y + sdy), axis=-1)
+    return float((pxy - px - py).mean())

@@ -218,6 +218,76 @@ def _rank_sum(t, group):
     return False
 
 
+def _rank_cat(t, group):
+    """Concatenation of `t` over the data-parallel ranks along dim 0 (rank order); `t` itself on a single rank."""
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return t
+    n = dist.get_world_size(group)
+    if t.is_cuda and dist.get_backend(group) == "gloo":  # test configuration: stage through the host
+        h = t.detach().cpu().contiguous()
+        parts = [torch.empty_like(h) for _ in range(n)]
+        dist.all_gather(parts, h, group=group)
+        return torch.cat(parts, 0).to(t.device)
+    t = t.detach().contiguous()
+    parts = [torch.empty_like(t) for _ in range(n)]
+    dist.all_gather(parts, t, group=group)
+    return torch.cat(parts, 0)
+
+
+class MutInfoEstimator(nn.Module):
+    """Kernel-density estimate of the mutual information between the latent means and the conditioning variables
+    (reference: disentangle.py:234-317; loss key `mcmi`, losses.py:221-225).  The mixture centres are the means /
+    conditions of the previous batch (trainer.py:184-199): p(x,y) = mean_s N(x; x_s, var_s) N(y; y_s, gamma), and the
+    value is mean_b[log p(x_b,y_b) - log p(x_b) - log p(y_b)] with the 1/num_s factors dropped exactly as the reference
+    drops them (its log-sum-exps are not normalised).  `var_mode="sphere"`: var_s = bandwidth; `"diagonal"`: var_s =
+    diag(L_s)^2 + bandwidth per centre.  O(B * num_s * (z + D)) on stock torch device ops, evaluated
+    in centre chunks so that the [B, num_s, z] difference tensor of the reference is never materialised whole;
+    train.losses seeds the HIP backward with d mcmi / d mu.  The reference's `device` argument only places its
+    constants; here they follow the centres."""
+
+    CHUNK = 256
+
+    def __init__(self, x_s, y_s, bandwidth, var_mode="sphere", model_var=None, device=None):
+        super().__init__()
+        import math
+        self.register_buffer("x_s", x_s)
+        self.register_buffer("y_s", y_s.to(x_s.dtype))
+        self.num_s, self.x_dim, self.y_dim = x_s.shape[0], x_s.shape[1], y_s.shape[1]
+        assert y_s.shape[0] == self.num_s
+        self.var_mode = var_mode
+        log2pi = math.log(2 * math.pi)
+        if var_mode == "sphere":
+            self.register_buffer("var_s", torch.tensor([bandwidth], device=x_s.device, dtype=x_s.dtype))
+            logA_x = self.x_dim * (log2pi + torch.log(self.var_s))                       # [1]
+        elif var_mode == "diagonal":
+            self.register_buffer("var_s", model_var.diagonal(dim1=-2, dim2=-1) ** 2 + bandwidth)   # [num_s, x_dim]
+            logA_x = (self.x_dim * log2pi + torch.sum(torch.log(self.var_s), dim=-1))[None, :]     # [1, num_s]
+        else:
+            raise ValueError(f"var_mode {var_mode!r} (the reference defines 'sphere' and 'diagonal')")
+        self.gamma = bandwidth
+        self.register_buffer("logA_x", logA_x)
+        self.register_buffer("logA_y", torch.tensor([self.y_dim * (log2pi + math.log(bandwidth))], device=x_s.device,
+                                                    dtype=x_s.dtype))
+
+    def forward(self, x, y):
+        y = y.to(x.dtype)
+        lse = [[], [], []]
+        for s0 in range(0, self.num_s, self.CHUNK):
+            s1 = min(s0 + self.CHUNK, self.num_s)
+            dx = x[:, None, :] - self.x_s[None, s0:s1, :]
+            dy = y[:, None, :] - self.y_s[None, s0:s1, :]
+            var = self.var_s if self.var_mode == "sphere" else self.var_s[None, s0:s1, :]
+            sdx = ((dx / var) * dx).sum(dim=-1)
+            sdy = ((dy / self.gamma) * dy).sum(dim=-1)
+            la = self.logA_x if self.var_mode == "sphere" else self.logA_x[:, s0:s1]
+            lse[0].append(torch.logsumexp(-0.5 * (la + self.logA_y + sdx + sdy), dim=-1))
+            lse[1].append(torch.logsumexp(-0.5 * (la + sdx), dim=-1))
+            lse[2].append(torch.logsumexp(-0.5 * (self.logA_y + sdy), dim=-1))
+        pxy, px, py = (torch.logsumexp(torch.stack(l, 0), dim=0) for l in lse)
+        return (pxy - px - py).mean()
+
+
 class MovingAverageFilter(nn.Module):
     """Streaming class-mean scrubber for a discrete variable (reference: disentangle.py:9-87; loss key `<feat>_ma`,
     losses.py:286-289).  Two exponentially-forgetting estimates of every class mean of the latent; the loss is the

@@ -41,7 +41,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     Bg = B * world  # losses are normalised by the GLOBAL batch so that summed grads match 1 GPU
     train = model.training and torch.is_grad_enabled()
     for k in loss_scale.keys():
-        if k in SUPPORTED or k.endswith(("_gr", "_an", "_mals", "_ma", "_qda", "_lsq")):
+        if k in SUPPORTED or k == "mcmi" or k.endswith(("_gr", "_an", "_mals", "_ma", "_qda", "_lsq")):
             continue
         raise NotImplementedError(f"loss '{k}' is outside this build's scope (SURVEY 8a: L5/A2 rows)")
     batch_loss = {}
@@ -103,6 +103,22 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     if train:
         d_mu.zero_()
     scrub = []
+    # ---- mcmi (losses.py:221-225): KDE mutual information between mu and the conditioning variables under the
+    # estimator built from the previous batch; zero (shaped like the jpe term, as in the reference) before the first refresh
+    if "mcmi" in loss_scale:
+        v = _scalar(model, "mcmi")
+        if model.mi_estimator is not None:
+            sc = float(loss_scale["mcmi"])
+            mu_t = st["mu"][:, :z].detach().clone().requires_grad_(bool(train and sc != 0))
+            with torch.enable_grad():
+                val = model.mi_estimator(mu_t, data_o["var"]) / world  # mean over the GLOBAL batch once summed over ranks
+            v.copy_(val.detach().reshape(1))
+            if train and sc != 0:
+                d_mu[:, :z] += sc * torch.autograd.grad(val, mu_t)[0]
+        else:
+            v.copy_(torch.zeros_like(batch_loss["jpe"]).reshape(1))
+        batch_loss["mcmi"] = v.view(()).clone()
+        add_total("mcmi", v)
     methods = disentangle_config["method"] if disentangle_config is not None else {}
     for method, keys in methods.items():
         nk = len(keys)

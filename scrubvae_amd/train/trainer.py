@@ -194,25 +194,44 @@ def train_test_epoch(config, model, loader, device, epoch, optimizer=None, sched
                             model.disentangle[method][k].update(data_o["mu"].detach().clone(), data[k].detach().clone())
             epoch_metrics = {k: v + batch_loss[k].detach() for k, v in epoch_metrics.items()}
             n_batches += 1
+            if "mcmi" in config["loss"].keys():
+                # refresh the mutual-information estimator from this batch, re-encoded with the updated weights
+                # (trainer.py:184-199); under data parallelism the centres of all ranks are gathered
+                updated = model.encode(data)
+                model.mi_estimator = make_mi_estimator(model, config, updated["mu"].detach().clone(), data_o["var"].clone(),
+                                                       updated["L"].detach().clone() if "L" in updated else None)
         for k, v in epoch_metrics.items():
             epoch_metrics[k] = (v.item() if torch.is_tensor(v) else float(v)) / max(n_batches, 1)
             print("====> Epoch: {} Average {} loss: {:.4f}".format(epoch, k, epoch_metrics[k]))
     return epoch_metrics
 
 
+def make_mi_estimator(model, config, mu, var, L):
+    from ..model.disentangle import MutInfoEstimator, _rank_cat
+    group = getattr(model, "process_group", None)
+    mu, var = _rank_cat(mu, group), _rank_cat(var, group)
+    L = _rank_cat(L, group) if L is not None else None
+    return MutInfoEstimator(x_s=mu, y_s=var, bandwidth=config["disentangle"]["bandwidth"],
+                            var_mode=config["disentangle"]["var_mode"], model_var=L, device=mu.device)
+
+
 def test_epoch(config, model, loader, device="cuda", epoch=0):
     """trainer.py:215-303: eval-mode pass over `loader` -> (epoch_metrics incl. r2_gen_restrict_<key>, mu [N,z] on
-    the CPU).  The `mcmi` estimator refresh (trainer.py:230-256) belongs to the streaming-scrubber row (SURVEY 8a
-    A2 / 8f N4) and raises here rather than silently skipping."""
+    the CPU).  With an `mcmi` loss the mutual-information estimator is first rebuilt from a strided sample of the
+    dataset (trainer.py:228-252)."""
     from sklearn.metrics import r2_score
 
     from ..eval import generative_restrictiveness
     print("Running test epoch")
-    if "mcmi" in config["loss"].keys():
-        raise NotImplementedError("test_epoch: the mcmi mutual-information estimator is not on the HIP path (SURVEY 8f N4)")
     model.eval()
     with torch.no_grad():
         z = []
+        if "mcmi" in config["loss"].keys():
+            sample = loader.dataset[:: int(len(loader.dataset) / config["data"]["batch_size"])]
+            enc = model.encode({k: v.to(device) for k, v in sample.items() if k in ["x6d", "root"]})
+            var = torch.cat([sample[k] for k in model.conditional_keys], dim=-1).to(device)
+            model.mi_estimator = make_mi_estimator(model, config, enc["mu"].detach().clone(), var,
+                                                   enc["L"].detach().clone() if "L" in enc else None)
         epoch_metrics = {k: 0 for k in ["total"] + list(config["loss"].keys())}
         gen_res = {k1: {k2: [] for k2 in ["pred", "target"]} for k1 in model.disentangle_keys if k1 != "ids"}
         n_batches = 0

@@ -214,3 +214,46 @@ def test_gloo_world2_class_filters_match_one_rank(which):
             assert torch.allclose(torch.from_numpy(res[r][1][k]), v, rtol=2e-4, atol=1e-5), (r, k)
     got = res[0][0] if which == "MovingAverageFilter" else res[0][0] + res[1][0]
     assert abs(got - want) <= 2e-4 * abs(want) + 1e-5
+
+
+def _mi_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    parallel.init_distributed(backend="gloo")
+    try:
+        from types import SimpleNamespace
+        from scrubvae_amd.train.trainer import make_mi_estimator
+        g = torch.Generator().manual_seed(4)
+        mu, var, x, y = (torch.randn(32, 6, generator=g), torch.randn(32, 3, generator=g), torch.randn(32, 6, generator=g),
+                         torch.randn(32, 3, generator=g))
+        L = torch.diag_embed(torch.rand(32, 6, generator=g) + 0.3)
+        lo, hi = parallel.shard_range(32, rank, world)
+        cfg = {"disentangle": {"bandwidth": 0.6, "var_mode": "diagonal"}}
+        est = make_mi_estimator(SimpleNamespace(process_group=None), cfg, mu[lo:hi], var[lo:hi], L[lo:hi])
+        # losses.get_batch_loss divides the rank-local mean by the world size; the rank values then add up
+        q.put((rank, float(est(x[lo:hi], y[lo:hi])) / world, est.num_s))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_mcmi_estimator_matches_one_rank():
+    """The KDE centres of every rank are gathered, so 2 ranks with half batches evaluate the estimator of 1 rank with the
+    batch; rank-local means / world add up to the global mean."""
+    from scrubvae_amd.model.disentangle import MutInfoEstimator
+    g = torch.Generator().manual_seed(4)
+    mu, var, x, y = (torch.randn(32, 6, generator=g), torch.randn(32, 3, generator=g), torch.randn(32, 6, generator=g),
+                     torch.randn(32, 3, generator=g))
+    L = torch.diag_embed(torch.rand(32, 6, generator=g) + 0.3)
+    want = float(MutInfoEstimator(mu, var, 0.6, var_mode="diagonal", model_var=L)(x, y))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mi_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[2] == 32 for r in res)
+    assert abs(sum(r[1] for r in res) - want) < 1e-5 * abs(want)
