@@ -189,6 +189,8 @@ def init_state_dict(cfg: OracleConfig, seed=0, dtype=torch.float32, scale=1.0):
         ensemble(f"disentangle.grad_reversal.{feat}.reversal.1", cfg.z_dim, cfg.feat_dim(feat))
     for feat in cfg.method.get("adversarial_net", []):
         ensemble(f"disentangle.adversarial_net.{feat}.ensemble", cfg.z_dim + cfg.conditional_dim, 2)
+    for feat in cfg.method.get("linear", []):  # LinearProjection(bias=False), get/model.py:40-49
+        sd[f"disentangle.linear.{feat}.decoder.weight"] = rnd(cfg.feat_dim(feat), cfg.z_dim, fan=cfg.z_dim)
     return sd
 
 
@@ -376,17 +378,30 @@ def forward(sd, cfg, data, train, eps=None, new_stats=None):
     out["z"] = z
     out.update(decode(sd, cfg, z, data, train, new_stats))
     out["disentangle"] = {}
+    if "linear" in cfg.method:  # residual.py:339-344
+        out["disentangle"]["linear"] = {k: linear_projection(out["mu"], sd[f"disentangle.linear.{k}.decoder.weight"])
+                                        for k in cfg.method["linear"]}
     for method, feats in cfg.method.items():
-        if method in ("conditional",):
+        if method in ("conditional", "linear"):
             continue
         out["disentangle"][method] = {}
         for k in feats:
+            # residual.py:351-355: with `linear` configured the heads read the feature's null-space projection
+            latent = out["disentangle"]["linear"][k]["z_null"] if "linear" in cfg.method else out["mu"]
             if method == "grad_reversal":
                 out["disentangle"][method][k] = mlp_ensemble(
-                    sd, f"disentangle.grad_reversal.{k}.reversal.1", _GradReverse.apply(out["mu"], cfg.alpha))
+                    sd, f"disentangle.grad_reversal.{k}.reversal.1", _GradReverse.apply(latent, cfg.alpha))
             elif method == "adversarial_net":
-                out["disentangle"][method][k] = adv_forward(sd, k, out["mu"], out["var"])
+                out["disentangle"][method][k] = adv_forward(sd, k, latent, out["var"])
     return out
+
+
+def linear_projection(z, w):
+    """LinearProjection.forward (disentangle.py:727-734) with the textbook projector: v = z W^T and
+    z_null = z (I - W^T (W W^T)^-1 W), the component of z orthogonal to the rows of W [out, z]."""
+    v = z @ w.T
+    proj = torch.eye(w.shape[1], dtype=w.dtype) - w.T @ torch.linalg.inv(w @ w.T) @ w
+    return {"v": v, "z_null": z @ proj}
 
 
 # --------------------------------------------------------------------------- pose maths
@@ -497,6 +512,8 @@ def batch_loss(sd, cfg, data, out, loss_scale, adv_perm=None):
                 for ye in y_pred:
                     acc = acc + F.cross_entropy(ye, y, reduction="sum")  # CE on softmax output (quirk)
                 bl[key + "_an"] = acc / (-(len(y_pred) * B))
+            if method == "linear":  # losses.py:258-265
+                bl[key + "_lin"] = torch.sum((out["disentangle"]["linear"][key]["v"] - data[key]) ** 2) / nk / B
     if "total_correlation" in loss_scale:
         bl["total_correlation"] = total_correlation(out["z"], out["mu"], out["L"])
     bl["total"] = sum(loss_scale[k] * bl[k] for k in list(bl.keys()) if loss_scale[k] != 0)

@@ -9,8 +9,8 @@ FEAT_DIMS = {"avg_speed": 1, "part_speed": 4, "avg_speed_3d": 3, "heading": 2, "
 
 def model(model_config, load_model, epoch, disentangle_config, n_keypts, direction_process, loss_config=None,
           arena_size=None, kinematic_tree=None, bound=False, discrete_classes=None, device="cuda", verbose=1):
-    from scrubvae_amd.model.disentangle import (AdvNetScrubber, GRScrubber, MovingAverageFilter, MovingAvgLeastSquares,
-                                                QuadraticDiscriminantFilter)
+    from scrubvae_amd.model.disentangle import (AdvNetScrubber, GRScrubber, LinearProjection, MovingAverageFilter,
+                                                MovingAvgLeastSquares, QuadraticDiscriminantFilter)
     from scrubvae_amd.model.residual import ResVAE
 
     feat_dim_dict = dict(FEAT_DIMS)
@@ -23,10 +23,6 @@ def model(model_config, load_model, epoch, disentangle_config, n_keypts, directi
         in_channels += 3
 
     methods = disentangle_config["method"] or {}
-    for unsupported in ("linear",):
-        if unsupported in methods:
-            raise NotImplementedError(
-                f"disentangle method '{unsupported}' is outside this build's scope (SURVEY.md 8a row A2 / 8f N4)")
     if "conditional" in methods:
         conditional_dim = sum(feat_dim_dict[k] for k in methods["conditional"])
         conditional_keys = methods["conditional"]
@@ -34,6 +30,9 @@ def model(model_config, load_model, epoch, disentangle_config, n_keypts, directi
         conditional_keys, conditional_dim = None, 0
 
     disentangle = {}
+    if "linear" in methods:  # get/model.py:40-49; first, as in the reference (the other heads then read z_null)
+        disentangle["linear"] = {feat: LinearProjection(model_config["z_dim"], feat_dim_dict[feat], bias=False)
+                                 for feat in methods["linear"]}
     if "grad_reversal" in methods:
         disentangle["grad_reversal"] = {
             feat: GRScrubber(model_config["z_dim"], feat_dim_dict[feat], alpha=disentangle_config["alpha"], bound=bound)

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..ops import pad16
-from .layers import LinearP, Marker
+from .layers import DenseW, LinearP, Marker
 
 
 def _mlp(dims):
@@ -216,6 +216,31 @@ def _rank_sum(t, group):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return True
     return False
+
+
+class LinearProjection(nn.Module):
+    """Linear decoder of one feature plus the projection of the latent onto the decoder's null space (reference:
+    disentangle.py:717-734; method `linear`, loss key `<feat>_lin`, losses.py:258-265): v = z Wt (+ b),
+    z_null = z - (W Wt)^-1 v ... W, i.e. z minus its component in the row space of W.  When the method is configured every
+    other scrubber of that feature reads z_null instead of mu (residual.py:351-355, losses.py:232-235).  A [out x out]
+    solve and two [B x z] products: stock torch device ops; the model keeps the small autograd graph and
+    train.losses / the HIP backward differentiate through it to mu and to `decoder.weight`."""
+
+    def __init__(self, in_dim, out_dim, bias=False):
+        super().__init__()
+        self.decoder = DenseW(in_dim, out_dim, bias=bias)
+
+    def leaves(self):
+        return [p for p in (self.decoder.weight, getattr(self.decoder, "bias", None)) if p is not None]
+
+    def forward(self, z):
+        w = self.decoder.weight
+        x = z @ w.T
+        if self.decoder.has_bias:
+            x = x + self.decoder.bias
+        nrm = w @ w.T
+        z_null = z - torch.linalg.solve(nrm, x.T).T @ w
+        return {"v": x, "z_null": z_null}
 
 
 def _rank_cat(t, group):

@@ -100,6 +100,26 @@ class ConvP(Leaf):
         return f"{self.c_in}, {self.c_out}, kernel={self.kernel}, stride={self.stride}, padding={self.padding}, transposed={self.transposed}"
 
 
+class DenseW(Leaf):
+    """nn.Linear parameters kept in the reference layout ([out, in], optional bias): used by heads that run on torch
+    device ops (LinearProjection) but still live in the flat parameter / gradient buffers."""
+
+    def __init__(self, in_f, out_f, bias=False):
+        super().__init__()
+        self.in_f, self.out_f, self.has_bias = in_f, out_f, bias
+        self.declare("weight", (out_f, in_f))
+        if bias:
+            self.declare("bias", (out_f,))
+
+    def reset_parameters(self):
+        w = torch.empty(self.out_f, self.in_f)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        with torch.no_grad():
+            self.weight.copy_(w.to(self.weight.device))
+            if self.has_bias:
+                self.bias.copy_(torch.empty(self.out_f).uniform_(-1 / math.sqrt(self.in_f), 1 / math.sqrt(self.in_f)).to(self.bias.device))
+
+
 def _index_map(n_ref, index):
     """lib->ref index map padded to a multiple of 16 with -1."""
     if index is None:

@@ -643,27 +643,47 @@ class ResVAE(nn.Module):
         data_o["x6d"] = x6d_hat
         if root_hat is not None:
             data_o["root"] = root_hat
-        # scrubber heads (all take mu, residual.py:337-360)
+        # scrubber heads (residual.py:337-360): they take mu, or -- when the `linear` method is configured -- the feature's
+        # null-space projection z_null of mu
         data_o["disentangle"] = {}
+        lin = None
+        if "linear" in self.disentangle:
+            need = self.training and torch.is_grad_enabled()
+            mu_leaf = mu[:, : self.z_dim].detach().clone().requires_grad_(need)
+            with torch.set_grad_enabled(need):
+                outs = {k: m(mu_leaf) for k, m in self.disentangle["linear"].items()}
+            data_o["disentangle"]["linear"] = outs
+            lin = dict(mu=mu_leaf, out=outs, leaves={k: [mu_leaf] + m.leaves() for k, m in self.disentangle["linear"].items()})
+
+        def latent(k):
+            """[B, zp] buffer the HIP heads of feature k read"""
+            if lin is None:
+                return mu
+            x = self._buf(f"lin.{k}.zn", (B, pad16(self.z_dim)), zero=True)
+            x[:, : self.z_dim] = lin["out"][k]["z_null"].detach()  # KeyError for a feature without projection, as in the reference
+            return x
+
         for method, module_dict in self.disentangle.items():
+            if method == "linear":
+                continue
             data_o["disentangle"][method] = {}
             for k, m in module_dict.items():
                 if method == "grad_reversal":
-                    outs = self._runner(method, k, m.ensemble, B).forward(mu)
+                    outs = self._runner(method, k, m.ensemble, B).forward(latent(k))
                     data_o["disentangle"][method][k] = [o[:, : m.ensemble.out_dim] for o in outs]
                 elif method == "adversarial_net":
                     x = self._buf(f"an.{k}.x0", (B, pad16(m.ensemble.in_dim)), zero=True)
-                    x[:, : self.z_dim] = mu[:, : self.z_dim]
+                    x[:, : self.z_dim] = latent(k)[:, : self.z_dim]
                     x[:, self.z_dim: self.z_dim + self.conditional_dim] = data_o["var"]
                     outs = self._runner(method + ".fwd", k, m.ensemble, B).forward(x)
                     data_o["disentangle"][method][k] = [torch.softmax(o[:, :2], -1) for o in outs]
                 elif method == "moving_avg_lsq":
-                    data_o["disentangle"][method][k] = m(mu[:, : self.z_dim])
+                    data_o["disentangle"][method][k] = m(latent(k)[:, : self.z_dim])
                 elif method in ("moving_avg", "qda"):  # stateful filters: forward() is a no-op (disentangle.py:31-32,127-128)
-                    data_o["disentangle"][method][k] = m(mu[:, : self.z_dim])
+                    data_o["disentangle"][method][k] = m(latent(k)[:, : self.z_dim])
                 else:
                     raise NotImplementedError(f"scrubber '{method}' is outside this build's scope (SURVEY 8a row A2)")
-        self._state = dict(B=B, flat=flat, h=h, eps=eps, mu=mu, sigma=sigma, zc=zc, klp=klp, data=data)
+        self._state = dict(B=B, flat=flat, h=h, eps=eps, mu=mu, sigma=sigma, zc=zc, klp=klp, data=data, lin=lin)
         return data_o
 
     def _runner(self, method, key, ens: MLPEnsemble, rows):
@@ -694,10 +714,24 @@ class ResVAE(nn.Module):
         zp = pad16(self.z_dim)
         d_mu = pend["d_mu"]  # [B, zp] zero-initialised seed for scrubber grads
         # ---- scrubber heads: MLP backward, seeds into d_mu
+        # `linear` projections: gradients of their decoders come from the small torch graphs (train.losses collected the
+        # loss-side part; the gradient-reversal heads add theirs below)
+        if "linear" in self.disentangle and not acc:
+            for m in self.disentangle["linear"].values():
+                for p in m.leaves():
+                    p.grad.zero_()
+        for p, g in pend.get("lin_pgrads", {}).values():
+            p.grad.add_(g)
         for item in pend["scrub"]:
             runner, d_outs, kind = item["runner"], item["d_outs"], item["kind"]
             g_in = runner.backward(d_outs, param_grads=(kind == "gr"), accumulate=acc)
-            if kind == "gr":
+            if kind == "gr" and item.get("lin") is not None:  # head input was z_null(mu, W): chain through the projection
+                z_null, leaves = item["lin"]
+                gs = torch.autograd.grad(z_null, leaves, grad_outputs=-item["alpha"] * g_in[:, : self.z_dim], retain_graph=True)
+                d_mu[:, : self.z_dim] += gs[0]
+                for p, g in zip(leaves[1:], gs[1:]):
+                    p.grad.add_(g)
+            elif kind == "gr":
                 ops.axpy(-item["alpha"], g_in, d_mu)  # gradient reversal: -alpha * grad
             else:  # adversarial net on cat([mu;mu],[v;v_shuffle]): both halves feed mu
                 tmp = self._buf("an.gmu", (B, zp), zero=True)

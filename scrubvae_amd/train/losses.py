@@ -41,7 +41,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     Bg = B * world  # losses are normalised by the GLOBAL batch so that summed grads match 1 GPU
     train = model.training and torch.is_grad_enabled()
     for k in loss_scale.keys():
-        if k in SUPPORTED or k == "mcmi" or k.endswith(("_gr", "_an", "_mals", "_ma", "_qda", "_lsq")):
+        if k in SUPPORTED or k == "mcmi" or k.endswith(("_gr", "_an", "_mals", "_ma", "_qda", "_lsq", "_lin")):
             continue
         raise NotImplementedError(f"loss '{k}' is outside this build's scope (SURVEY 8a: L5/A2 rows)")
     batch_loss = {}
@@ -103,6 +103,32 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     if train:
         d_mu.zero_()
     scrub = []
+    # `linear` method: every other scrubber of a feature reads the null-space projection z_null(mu, W) of that feature
+    # instead of mu (losses.py:232-235); gradients then go through the projection's torch graph to mu and to its decoder
+    lin = st.get("lin")
+    lin_pgrads = {}
+
+    def latent_graph(key):
+        """(latent [B, z] to evaluate a torch-graph loss on, leaves to differentiate with respect to; leaves[0] is mu)"""
+        if lin is not None:
+            return lin["out"][key]["z_null"], lin["leaves"][key]
+        t = st["mu"][:, :z].detach().clone().requires_grad_(bool(train))
+        return t, [t]
+
+    def push(leaves, grads, sc=1.0):
+        d_mu[:, :z] += sc * grads[0]
+        for p, g in zip(leaves[1:], grads[1:]):
+            if g is not None:
+                lin_pgrads[id(p)] = (p, lin_pgrads[id(p)][1] + sc * g if id(p) in lin_pgrads else sc * g)
+
+    def push_latent_seed(key, seed):
+        """seed = d total / d latent [B, z] (analytic)"""
+        if lin is None:
+            d_mu[:, :z] += seed
+        else:
+            lat, leaves = latent_graph(key)
+            push(leaves, torch.autograd.grad(lat, leaves, grad_outputs=seed, retain_graph=True, allow_unused=True))
+
     # ---- mcmi (losses.py:221-225): KDE mutual information between mu and the conditioning variables under the
     # estimator built from the previous batch; zero (shaped like the jpe term, as in the reference) before the first refresh
     if "mcmi" in loss_scale:
@@ -152,7 +178,8 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 batch_loss[lk] = v.view(()).clone()
                 add_total(lk, v)
                 if train and loss_scale[lk] != 0:
-                    scrub.append(dict(kind="gr", runner=runner, d_outs=d_outs, alpha=m.alpha))
+                    scrub.append(dict(kind="gr", runner=runner, d_outs=d_outs, alpha=m.alpha,
+                                      lin=None if lin is None else (lin["out"][key]["z_null"], lin["leaves"][key])))
             elif method == "adversarial_net":
                 m = model.disentangle[method][key]
                 v_ind = model.disentangle_keys.index(key)
@@ -198,11 +225,11 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                     if train and loss_scale[lk] != 0:  # d/d mu of scale * (l0 + l1) / (2 Bg), decoders W constant
                         W0, W1 = m._W
                         zin = m.nx_in
-                        d_mu[:, :zin] += (float(loss_scale[lk]) / Bg) * ((y0 - tgt) @ W0[:zin].T + (y1 - tgt) @ W1[:zin].T)
+                        push_latent_seed(key, (float(loss_scale[lk]) / Bg) * ((y0 - tgt) @ W0[:zin].T + (y1 - tgt) @ W1[:zin].T))
             elif method == "direct_lsq":  # direct_lsq_loss, losses.py:173-179,254-257: stateless least-squares decoder
                 lk = key + "_lsq"
                 sc = float(loss_scale[lk])
-                zm = st["mu"][:, :z]
+                zm = st["mu"][:, :z] if lin is None else lin["out"][key]["z_null"].detach()
                 if sc < 0:  # bias column
                     zm = torch.column_stack((zm, torch.ones(B, 1, device=zm.device)))
                 tgt = model._prep(data[key])
@@ -219,14 +246,14 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 if train and sc != 0:
                     # d/d mu of the summed squared residual: the decoder is the minimiser, so its own dependence on mu
                     # contributes nothing (dL/dW = 0) and the gradient is 2 * res * W^T
-                    d_mu[:, :z] += (2.0 * sc) * (res @ Wd[:z].T)
+                    push_latent_seed(key, (2.0 * sc) * (res @ Wd[:z].T))
             elif method in ("moving_avg", "qda"):  # losses.py:248-252,286-289
                 m = model.disentangle[method][key]
                 lk = key + ("_ma" if method == "moving_avg" else "_qda")
                 sc = float(loss_scale.get(lk, 0.0))
-                mu_t = st["mu"][:, :z].detach().clone().requires_grad_(bool(train and sc != 0))
+                mu_t, leaves = latent_graph(key)
                 tgt = data[key].to(model.device)
-                with torch.enable_grad():
+                with torch.set_grad_enabled(bool(train and sc != 0)):
                     val = m.evaluate_loss(mu_t, tgt)
                     if method == "qda":
                         val = val / Bg
@@ -236,7 +263,22 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 if lk in loss_scale:
                     add_total(lk, v)
                     if train and sc != 0:  # seed of the HIP backward: d(scale * loss) / d mu through the small torch graph
-                        d_mu[:, :z] += sc * torch.autograd.grad(val, mu_t)[0]
+                        push(leaves, torch.autograd.grad(val, leaves, retain_graph=lin is not None, allow_unused=True), sc)
+            elif method == "linear":  # losses.py:258-265: the projection's own decoder regresses the feature
+                lk = key + "_lin"
+                sc = float(loss_scale.get(lk, 0.0))
+                pred = lin["out"][key]["v"]
+                tgt = model._prep(data[key])
+                with torch.set_grad_enabled(bool(train and sc != 0)):
+                    val = ((pred - tgt) ** 2).sum() / nk / Bg
+                v = _scalar(model, lk)
+                v.copy_(val.detach().reshape(1))
+                batch_loss[lk] = v.view(()).clone()
+                if lk in loss_scale:
+                    add_total(lk, v)
+                    if train and sc != 0:
+                        leaves = lin["leaves"][key]
+                        push(leaves, torch.autograd.grad(val, leaves, retain_graph=True, allow_unused=True), sc)
             else:
                 raise NotImplementedError(f"scrubber '{method}' is outside this build's scope (SURVEY 8a row A2)")
 
@@ -265,7 +307,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 ops.tc_bwd(zc, zcp, mu_b, zp, lv, B, z, lse_l, lse_a, w, d_mu, zp, dlv, z)
 
     if train:
-        model._pending = dict(dy=dy, kl_scale=kl_scale, d_mu=d_mu, scrub=scrub, dsigma=dsigma, dlv=dlv,
+        model._pending = dict(dy=dy, kl_scale=kl_scale, d_mu=d_mu, scrub=scrub, dsigma=dsigma, dlv=dlv, lin_pgrads=lin_pgrads,
                               accumulate=getattr(model, "accumulate_grads", False))
         batch_loss["total"] = model.make_total(total.view(()))
     else:

@@ -38,6 +38,10 @@ SCENARIOS = {
                        {"jpe": 1.0, "root": 1.0, "prior": 0.5, "ids_gr": 1.0}, "adam"),
     "vanilla_default_B4": (O.OracleConfig(n_keypts=18, window=64, z_dim=32, kernel=5, diag=True, arena_size=ARENA),
                            {"jpe": 1.0, "root": 1.0, "prior": 1.0}, "adamw"),
+    "linear_gr_tiny": (O.OracleConfig(diag=True, method={"linear": ["avg_speed_3d", "heading"], "grad_reversal": ["avg_speed_3d", "heading"]},
+                                      features=["avg_speed_3d", "heading"], **TINY),
+                       {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_lin": 0.6, "heading_lin": 1.5,
+                        "avg_speed_3d_gr": 1.0, "heading_gr": 2.0}, "adamw"),
     # BASELINE config 5's shape: window 256; four blocks = the unmodified reference, six blocks = the
     # reference with only its default dilation list lengthened (it cannot build >4 blocks otherwise,
     # see make_fixtures.py)
@@ -81,7 +85,8 @@ def test_oracle_step0_matches_reference(golden_dir, name):
             assert rel(bl[k[8:]], fx[k]) < 2e-5, k
         if k.startswith("s0/out/disentangle/"):
             _, _, _, method, feat, i = k.split("/")
-            assert rel(out["disentangle"][method][feat][int(i)].detach(), fx[k]) < 2e-5, k
+            got = out["disentangle"][method][feat]
+            assert rel((got[i] if method == "linear" else got[int(i)]).detach(), fx[k]) < 2e-5, k
     gmax = float(fx["s0/grad_absmax"])
     tot = 0.0
     for k in fx.files:
@@ -98,7 +103,7 @@ def test_oracle_step0_matches_reference(golden_dir, name):
     assert rel(gn, fx["s0/grad_norm"]) < (1e-2 if "rotation" in loss_scale else 1e-3)
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "linear_gr_tiny"])
 def test_oracle_multistep_and_eval(golden_dir, name):
     """3 optimizer steps then an eval-mode forward.  Adam amplifies fp32 noise (sign-like
     first step), the reference run at 1 vs 8 threads diverges ~1e-5/step: gate 2e-3."""
