@@ -655,15 +655,25 @@ def generative_restrictiveness(sd, cfg, z, data, key, rand):
 
 
 # ------------------------------------------------------- streaming scrubber
-def mals_init(nx, ny, bias=False, lamdiff=1e-1, dtype=torch.float32):
-    """MovingAvgLeastSquares.__init__, disentangle.py:393-438 (polynomial_order 1)."""
-    n = nx + int(bias)
+def mals_init(nx, ny, bias=False, lamdiff=1e-1, dtype=torch.float32, polynomial_order=1):
+    """MovingAvgLeastSquares.__init__, disentangle.py:393-438: the design has C(nx+d-1, d) columns per degree d."""
+    n = sum(math.comb(nx + d - 1, d) for d in range(1, polynomial_order + 1)) + int(bias)
     return {"Sxx0": torch.eye(n, dtype=dtype), "Sxy0": torch.zeros(n, ny, dtype=dtype), "Sxx1": torch.eye(n, dtype=dtype),
             "Sxy1": torch.zeros(n, ny, dtype=dtype), "lam0": torch.tensor([0.9], dtype=dtype),
-            "lam1": torch.tensor([0.9], dtype=dtype) + lamdiff, "bias": bias, "lamdiff": lamdiff}
+            "lam1": torch.tensor([0.9], dtype=dtype) + lamdiff, "bias": bias, "lamdiff": lamdiff, "poly": polynomial_order}
 
 
 def _mals_design(st, x):
+    """polynomial_expansion (disentangle.py:440-464) + bias column: degree-d block = products over every multiset of d
+    latent dimensions (itertools order == torch.combinations(with_replacement=True)), times nx / (block width)."""
+    import itertools
+    nx = x.shape[1]
+    cols = [x]
+    for d in range(2, st.get("poly", 1) + 1):
+        combos = list(itertools.combinations_with_replacement(range(nx), d))
+        block = torch.stack([torch.stack([x[:, i] for i in c], 0).prod(0) for c in combos], 1)
+        cols.append(block / len(combos) * nx)
+    x = torch.column_stack(cols)
     return torch.column_stack((x, torch.ones(x.shape[0], 1, dtype=x.dtype))) if st["bias"] else x
 
 

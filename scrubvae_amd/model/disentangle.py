@@ -137,16 +137,18 @@ class MovingAvgLeastSquares(nn.Module):
     the two squared errors and nudges the forgetting factors toward the better decoder, `update` folds a batch into
     the covariances.  These are [z x z] solves and [B x z] products on device tensors -- stock torch ops behind the
     reference API, as SURVEY 8a allows for this row; the gradient into the encoder is seeded analytically by
-    train.losses (the decoders W are constants of the step).  polynomial_order > 1 is not built."""
+    train.losses (the decoders W are constants of the step).  `polynomial_order` p > 1 appends, for every degree
+    d = 2..p, the products of all size-d multisets of latent dimensions scaled by nx / (number of such products)
+    (disentangle.py:440-464); the seed then also goes through the expansion's Jacobian."""
 
     def __init__(self, nx, ny, lamdiff=1e-1, delta=1e-4, bias=False, polynomial_order=1, l2_reg=0):
         super().__init__()
-        if polynomial_order != 1:
-            raise NotImplementedError("MovingAvgLeastSquares: polynomial_order > 1 is not built (SURVEY 8f N4)")
+        import math
         self.bias = bool(bias)
-        self.polynomial_order = 1
+        self.polynomial_order = int(polynomial_order)
         self.nx_in = int(nx)
-        nx = int(nx) + int(self.bias)
+        self.nx_poly = sum(math.comb(int(nx) + d - 1, d) for d in range(1, self.polynomial_order + 1))
+        nx = self.nx_poly + int(self.bias)
         self.l2_reg = 0 if l2_reg is None else l2_reg
         print("Moving Avg Least Squares Bias: {}".format(self.bias))
         self.register_buffer("Sxx0", torch.eye(nx))
@@ -160,8 +162,16 @@ class MovingAvgLeastSquares(nn.Module):
         self.process_group = None  # set by parallel.attach: batch statistics are summed over the ranks
         self._W = None
 
+    def polynomial_expansion(self, x):
+        cols = [x]
+        idx = torch.arange(x.shape[1], dtype=torch.long, device=x.device)
+        for d in range(2, self.polynomial_order + 1):
+            c = torch.combinations(idx, d, with_replacement=True)
+            cols.append(x[:, c].prod(dim=-1) / len(c) * x.shape[-1])
+        return torch.column_stack(cols) if len(cols) > 1 else x
+
     def _design(self, x):
-        x = x[:, : self.nx_in]
+        x = self.polynomial_expansion(x[:, : self.nx_in])
         if self.bias:
             x = torch.column_stack((x, torch.ones(x.shape[0], 1, device=x.device)))
         return x
@@ -175,6 +185,19 @@ class MovingAvgLeastSquares(nn.Module):
         W1 = torch.linalg.solve(self.Sxx1.diagonal_scatter(self.Sxx1.diagonal() + l2), self.Sxy1)
         self._W = (W0, W1)
         return [x @ W0, x @ W1]
+
+    def latent_seed(self, yhat0, yhat1, y, x, scale):
+        """scale * d[(l0 + l1) / 2] / d x for the predictions of the last forward(x), the decoders W held constant:
+        ((yhat0 - y) W0^T + (yhat1 - y) W1^T) on the design columns, chained through the polynomial expansion's Jacobian
+        when there is one."""
+        W0, W1 = self._W
+        n = self.nx_poly
+        seed = scale * ((yhat0 - y) @ W0[:n].T + (yhat1 - y) @ W1[:n].T)
+        if self.polynomial_order > 1:
+            lat = x[:, : self.nx_in].detach().clone().requires_grad_(True)
+            with torch.enable_grad():
+                seed = torch.autograd.grad(self.polynomial_expansion(lat), lat, grad_outputs=seed)[0]
+        return seed
 
     def _allreduce(self, t):
         _rank_sum(t, self.process_group)

@@ -223,9 +223,9 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 if lk in loss_scale:
                     add_total(lk, v)
                     if train and loss_scale[lk] != 0:  # d/d mu of scale * (l0 + l1) / (2 Bg), decoders W constant
-                        W0, W1 = m._W
-                        zin = m.nx_in
-                        push_latent_seed(key, (float(loss_scale[lk]) / Bg) * ((y0 - tgt) @ W0[:zin].T + (y1 - tgt) @ W1[:zin].T))
+                        lat = st["mu"][:, : m.nx_in] if lin is None else lin["out"][key]["z_null"]
+                        seed = m.latent_seed(y0, y1, tgt, lat.detach(), float(loss_scale[lk]) / Bg)
+                        push_latent_seed(key, seed)
             elif method == "direct_lsq":  # direct_lsq_loss, losses.py:173-179,254-257: stateless least-squares decoder
                 lk = key + "_lsq"
                 sc = float(loss_scale[lk])

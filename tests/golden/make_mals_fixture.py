@@ -27,25 +27,24 @@ FEATS = ["avg_speed_3d", "heading"]
 LOSS = {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_mals": -0.7, "heading_mals": 0.3}
 
 
-def main():
-    get_model, get_batch_loss, predict_batch = MF.import_reference()
+def main(refs, name="mals_tiny", polynomial=1, l2_reg=0):
+    get_model, get_batch_loss, predict_batch = refs
     arena = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
     cfg = O.OracleConfig(diag=True, method={"moving_avg_lsq": FEATS}, features=FEATS, n_keypts=18, window=64, z_dim=8,
                          kernel=5, channel=(8, 8, 16, 16, 32), arena_size=arena)
     B, n_steps, lr = 8, 3, 1e-4
-    name = "mals_tiny"
-    sd = {k: v for k, v in O.init_state_dict(cfg, seed=len(name)).items() if not k.startswith("disentangle.")}
-    data = O.synth_batch(cfg, B, seed=len(name))
+    sd = {k: v for k, v in O.init_state_dict(cfg, seed=9).items() if not k.startswith("disentangle.")}
+    data = O.synth_batch(cfg, B, seed=9)
     g = torch.Generator().manual_seed(7)
     eps_all = [torch.randn(B, cfg.z_dim, generator=g) for _ in range(n_steps)]
     model_config = dict(type="rcnn", kernel=cfg.kernel, z_dim=cfg.z_dim, window=cfg.window, activation="prelu", diag=True,
                         init_dilation=None, prior="gaussian", channel=list(cfg.channel))
-    dis_config = dict(method=cfg.method, alpha=1.0, features=FEATS, polynomial=1, l2_reg=0)
+    dis_config = dict(method=cfg.method, alpha=1.0, features=FEATS, polynomial=polynomial, l2_reg=l2_reg)
     model = get_model(model_config, None, None, dis_config, cfg.n_keypts, "midfwd", loss_config=LOSS, arena_size=arena,
                       kinematic_tree=cfg.kinematic_tree, bound=False, discrete_classes=None, device="cpu", verbose=0)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected and all(m.startswith("disentangle.") for m in missing), (missing, unexpected)
-    fx = {"sd_seed": np.int64(len(name))}
+    fx = {"sd_seed": np.int64(9), "polynomial": np.int64(polynomial), "l2_reg": np.float64(l2_reg)}
     for k, v in data.items():
         fx["in/" + k] = v.numpy()
     for k, v in sd.items():
@@ -69,10 +68,9 @@ def main():
             p.grad = None
         bl["total"].backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1e6)
-        if step == 0:
-            for n, p in model.named_parameters():
-                if p.grad is not None and n.startswith("encoder.fc_mu"):
-                    fx["s0/grad/" + n] = p.grad.numpy().copy()
+        for n, p in model.named_parameters():  # from step 1 on (non-zero decoders) these carry d mals / d mu
+            if p.grad is not None and n.startswith("encoder.fc_mu"):
+                fx[f"s{step}/grad/" + n] = p.grad.numpy().copy()
         opt.step()
         torch.ones = cpu_ones
         try:
@@ -99,4 +97,6 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    refs = MF.import_reference()
+    main(refs)
+    main(refs, "mals_poly2_tiny", polynomial=2, l2_reg=0.05)
