@@ -46,7 +46,11 @@ def parse():
     ap.add_argument("--channels", default=",".join(map(str, CHANNELS)),
                     help="model.channel, comma separated; 'wide6' = configs[4]'s six blocks 64..4096 (use with --window 256)")
     ap.add_argument("--full", action="store_true", help="configs[2]: conditional + grad-reversal + adversarial heads")
-    ap.add_argument("--local-bn", action="store_true", help="per-rank BatchNorm statistics (no sync-BN collectives)")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N>1: all-reduce the BatchNorm batch statistics (32 small collectives per step) so that N ranks reproduce "
+                         "the 1-rank step at the global batch exactly; default = per-rank statistics, the semantics of "
+                         "torch DistributedDataParallel around the reference model")
+    ap.add_argument("--local-bn", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph (single GPU)")
     ap.add_argument("--precision", default=os.environ.get("SVAE_PRECISION", "bf16x6w3"), choices=list(PRODUCTS),
                     help="arithmetic of the large contractions: f32 = fp32 MFMA; bf16x6 = fp32-accurate 3-piece split on the bf16 "
@@ -173,7 +177,7 @@ def main():
     B = args.batch
     data, tree = synthetic.make_batch(args.joints, args.window, B, seed=100 + rank, device="cuda")
     model, dis = build_model(args, method, feats, tree)
-    parallel.attach(model, sync_bn=not args.local_bn)
+    parallel.attach(model, sync_bn=args.sync_bn)
     model.defer_tail = True  # one fused tail launch per step (outputs + losses + seed gradients)
     opt = FusedAdam(model, lr=1e-4, weight_decay=0.01, decoupled=True)
     model.train()
@@ -265,7 +269,7 @@ def main():
                                         " forward and data-gradient (fp32-accurate), 3 (2 pieces) for the weight-gradient contractions "
                                         "(gradient error vs fp64 unchanged, DESIGN.md 4)" if args.precision == "bf16x6w3" else " (reduced accuracy)")),
                        "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
-                       "parallelism": f"dp{world}" + ("" if world == 1 else ("+localbn" if args.local_bn else "+syncbn")),
+                       "parallelism": f"dp{world}" + ("" if world == 1 else ("+syncbn" if args.sync_bn else "+localbn")),
                        "final_total_loss": total_loss},
         }
         if timer is not None:

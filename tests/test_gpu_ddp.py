@@ -35,13 +35,13 @@ def _setup():
     return cfg, sd, data, eps
 
 
-def _run(model, dis, data, eps):
+def _run(model, dis, data, eps, ls=LS):
     from scrubvae_amd.train.losses import get_batch_loss
     model.train()
     d = {k: v.cuda() for k, v in data.items()}
     d["eps"] = eps.cuda()
     data_o = model(d)
-    bl = get_batch_loss(model, d, data_o, LS, dis)
+    bl = get_batch_loss(model, d, data_o, ls, dis)
     bl["total"].backward()
     torch.cuda.synchronize()
     return {k: float(v.detach()) for k, v in bl.items()}, model.flat_grads.detach().cpu().clone(), \
@@ -58,6 +58,7 @@ def _worker(rank, world, port, q):
         cfg, sd, data, eps = _setup()
         model, dis = build_model(cfg, sd)
         parallel.attach(model, sync_bn=True, broadcast=False)
+        model.bucket_min_bytes = 0  # every encoder block gets its own gradient bucket (the default merges small ones)
         lo, hi = parallel.shard_range(16, rank, world)
         shard = {k: v[lo:hi] for k, v in data.items()}
         losses, grads, stats = _run(model, dis, shard, eps[lo:hi])
@@ -98,3 +99,51 @@ def test_two_ranks_match_one_rank():
     assert float((grads - ref_grads).abs().max()) < 2e-3 * gmax
     rel = float((grads - ref_grads).norm() / ref_grads.norm())
     assert rel < 1e-3, rel
+
+
+def _rccl_worker(port, q):
+    """One rank on the RCCL backend: the collectives are identities, but every call of the data-parallel schedule --
+    sync-BN all-reduces, the gradient buckets fed from the communication stream, the final waits -- goes through
+    torch.distributed's RCCL process group exactly as on N GPUs."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    from scrubvae_amd import parallel
+    from tests.test_gpu_model import build_model
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        cfg, sd, data, eps = _setup()
+        out = {}
+        for mode in ("plain", "ddp"):
+            model, dis = build_model(cfg, sd)
+            if mode == "ddp":
+                parallel.attach(model, sync_bn=False, broadcast=True)
+                model.world_size = 2      # take the N>1 code path: every loss is then normalised by 2B
+                model.bucket_min_bytes = 0
+            losses, grads, stats = _run(model, dis, data, eps, ls={"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_gr": 0.0, "heading_gr": 0.0})
+            out[mode] = (losses, grads.numpy())
+        q.put(out)
+    except Exception as e:  # noqa: BLE001 -- reported to the parent instead of a queue timeout
+        import traceback
+        q.put({"error": traceback.format_exc()})
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_schedule_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=240)
+    p.join(timeout=60)
+    assert "error" not in out, out.get("error")
+    assert p.exitcode == 0
+    (l0, g0), (l1, g1) = out["plain"], out["ddp"]
+    g0, g1 = torch.from_numpy(g0), torch.from_numpy(g1)
+    # the faked world size halves every loss term and hence (local BatchNorm statistics) every gradient
+    for k, v in l0.items():
+        if not k.endswith("_gr"):  # recursive normalisation (losses.py:279-284): not linear in 1/B; scale 0 here
+            assert abs(2 * l1[k] - v) <= 1e-5 * abs(v), (k, l1[k], v)
+    assert float((2 * g1 - g0).abs().max()) <= 1e-4 * float(g0.abs().max())
