@@ -915,15 +915,21 @@ __global__ __launch_bounds__(256) void split_weights_batched_kernel(const SplitT
 // (image [piece][channel][16 k + pad], 48-byte rows: conflict-free ds_read_b128 operand fetches).
 constexpr int WSK = 16;
 constexpr int WROWB = 48;
+// rows outside the operand (conv padding, the tail past a split's last row) are read from here instead of being masked
+// after the load: no per-value selects, no validity flags carried in registers
+__device__ __attribute__((aligned(16))) float wgrad_zero_row[4] = {0.f, 0.f, 0.f, 0.f};  // not const: keeps the select in the global address space (global_load, not flat_load)
 
 // NSTAGE = 2: double-buffered LDS, one barrier per stage;  NSTAGE = 1: one buffer, two barriers, half the LDS
 // (more workgroups per CU overlap each other's conversion / LDS / MFMA phases)
 template <int BM, int BN, int P, int NSTAGE>
 __global__ __launch_bounds__(256, 2) void wgrad_gemm_bf16s_kernel(const WgradArgs g) {
   constexpr int WM = BM / 2, MT = WM / 32, WN = BN / 2, NT = WN / 32;
-  constexpr int A_PIECE = BM * WROWB, B_PIECE = BN * WROWB;
+  // channel row c of an operand image starts at c * 48 + (c / 16) * 16 bytes: the extra 16 B per 16 channels keep the
+  // staging writes of a 16-lane group (8 channel quads x 2 row groups, see below) on 32 different banks
+  constexpr int A_PIECE = BM * WROWB + BM, B_PIECE = BN * WROWB + BN;
   constexpr int STAGE = P * (A_PIECE + B_PIECE);
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+  auto lds_row = [](int c) { return c * WROWB + (c >> 4) * 16; };
 
   const int tid = threadIdx.x;
   const int ti = blockIdx.x / g.ctiles;
@@ -938,7 +944,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_bf16s_kernel(const WgradArg
   const bool is_a = tid < BM;
   const bool has_unit = tid < BM + BN;
   const int u = is_a ? tid : tid - BM;
-  const int rg = u & 3, cq = u >> 2;
+  // 16 consecutive lanes = 8 channel quads x 2 row groups: each quarter-wave of a global_load_dwordx4 reads two whole
+  // 128-B lines (8 quads x 16 B of two rows) instead of four half lines
+  const int q16 = u >> 4, l16 = u & 15;
+  const int nq8 = (is_a ? BM : BN) / 32;  // groups of 8 channel quads in the tile
+  const int cq = (l16 & 7) + 8 * (q16 % nq8);
+  const int rg = ((l16 >> 3) & 1) + 2 * (q16 / nq8);
   const int ch0 = (is_a ? c0 : n0) + cq * 4;
   const bool col_ok = has_unit && ch0 < (is_a ? g.Kc : g.N);
   const float* const base = is_a ? g.X : g.dY;
@@ -948,51 +959,61 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_bf16s_kernel(const WgradArg
   const int tb = is_a ? tbx : tby;
   const long long row_step = (long long)s * ld;                       // next reduction row, same sample
   const long long row_wrap = ((long long)L - (long long)g.nj * s) * ld;  // extra when j wraps into the next sample
-  const int q16 = WSK / g.nj, r16 = WSK % g.nj;
-  const long long st_step = ((long long)q16 * L + (long long)r16 * s) * ld;
-  int jj;
+  const int qs16 = WSK / g.nj, r16 = WSK % g.nj;
+  const long long st_step = ((long long)qs16 * L + (long long)r16 * s) * ld;
+  // running state of the first row of this thread's next tile: position in the sample jj, its X / dY rows, pointer, rows left
+  int jj, xr0, yr0, left;
   const float* ptr;
-  long long left;
   {
     const long long r = r_begin + rg * 4;
     const long long b = r / g.nj;
     jj = (int)(r - b * g.nj);
     ptr = base + (b * L + (long long)jj * s + tb) * (long long)ld + (col_ok ? ch0 : 0);
-    left = r_end - r;
+    const long long l = r_end - r;
+    left = l > 0x7fffffffLL ? 0x7fffffff : (int)l;
+    xr0 = jj * g.sx + tbx;
+    yr0 = jj * g.sy + tby;
   }
-  const int lds_unit = (is_a ? 0 : P * A_PIECE) + (cq * 4) * WROWB + rg * 8;
+  const int dx16 = r16 * g.sx, dy16 = r16 * g.sy, wrapx = g.nj * g.sx, wrapy = g.nj * g.sy;
+  const int lds_unit = (is_a ? 0 : P * A_PIECE) + lds_row(cq * 4) + rg * 8;
+  const float* const zero_row = wgrad_zero_row;
 
   float4 rv[4];
-  bool rv_ok[4];
+  // branch-free on purpose (bitwise &, selects): exec-mask branches here fence the MFMAs of the stage behind the whole
+  // address computation
   auto load_tile = [&]() {
-    int j = jj;
+    int j = jj, xr = xr0, yr = yr0;
     const float* p = ptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int xr = j * g.sx + tbx, yr = j * g.sy + tby;
-      const bool ok = col_ok && left > i && xr >= 0 && xr < g.Lx && yr >= 0 && yr < g.Ly;
-      rv[i] = *reinterpret_cast<const float4*>(ok ? p : base);
-      rv_ok[i] = ok;
+      const bool ok = col_ok & (left > i) & ((unsigned)xr < (unsigned)g.Lx) & ((unsigned)yr < (unsigned)g.Ly);
+      rv[i] = *reinterpret_cast<const float4*>(ok ? p : zero_row);
       ++j;
       p += row_step;
-      if (j >= g.nj) { j = 0; p += row_wrap; }
+      xr += g.sx;
+      yr += g.sy;
+      const bool wrap = j >= g.nj;
+      j = wrap ? 0 : j;
+      p += wrap ? row_wrap : 0;
+      xr = wrap ? tbx : xr;
+      yr = wrap ? tby : yr;
     }
     jj += r16;
     ptr += st_step;
     left -= WSK;
-    if (jj >= g.nj) { jj -= g.nj; ptr += row_wrap; }
+    xr0 += dx16;
+    yr0 += dy16;
+    const bool w2 = jj >= g.nj;
+    jj -= w2 ? g.nj : 0;
+    ptr += w2 ? row_wrap : 0;
+    xr0 -= w2 ? wrapx : 0;
+    yr0 -= w2 ? wrapy : 0;
   };
   auto store_tile = [&](int buf) {
     if (!has_unit) return;
     unsigned char* st = smem + buf * STAGE + lds_unit;
-    float v[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[i][0] = rv_ok[i] ? rv[i].x : 0.f;
-      v[i][1] = rv_ok[i] ? rv[i].y : 0.f;
-      v[i][2] = rv_ok[i] ? rv[i].z : 0.f;
-      v[i][3] = rv_ok[i] ? rv[i].w : 0.f;
-    }
+    const float v[4][4] = {{rv[0].x, rv[0].y, rv[0].z, rv[0].w}, {rv[1].x, rv[1].y, rv[1].z, rv[1].w},
+                           {rv[2].x, rv[2].y, rv[2].z, rv[2].w}, {rv[3].x, rv[3].y, rv[3].z, rv[3].w}};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       uint2 pc[P];
@@ -1022,21 +1043,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_bf16s_kernel(const WgradArg
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int p = 0; p < P; ++p)
-        av[mt][p] = *reinterpret_cast<const uint4*>(st + p * A_PIECE + (wr * WM + mt * 32 + lr) * WROWB + h * 16);
+        av[mt][p] = *reinterpret_cast<const uint4*>(st + p * A_PIECE + lds_row(wr * WM + mt * 32 + lr) + h * 16);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int p = 0; p < P; ++p)
-        bv[nt][p] = *reinterpret_cast<const uint4*>(st + P * A_PIECE + p * B_PIECE + (wc * WN + nt * 32 + lr) * WROWB + h * 16);
+        bv[nt][p] = *reinterpret_cast<const uint4*>(st + P * A_PIECE + p * B_PIECE + lds_row(wc * WN + nt * 32 + lr) + h * 16);
     mid();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_split<P>(av[mt], bv[nt], acc[mt][nt]);
   };
-  // loads / stores past the last tile are unconditional on purpose (rows past r_end read the
-  // operand base and stage zeros into a buffer nobody reads): conditional loads make hipcc wait
-  // vmcnt(0) and lose the prefetch distance
+  // loads / stores past the last tile are unconditional on purpose (rows past r_end read the zero row and stage zeros
+  // into a buffer nobody reads): conditional loads make hipcc wait vmcnt(0) and lose the prefetch distance
+  // Measured and NOT kept (MI355X, B=1024): issuing the next tile's loads before the stage's MFMAs
+  // (sched_barrier), and two register slots with loads a whole stage ahead of their use -- both +-0 to -10 %.
   if constexpr (NSTAGE == 2) {
     load_tile();
     store_tile(0);

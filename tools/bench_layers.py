@@ -9,6 +9,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 if len(sys.argv) > 2:
     ops.set_precision(sys.argv[2])  # f32 | bf16x6 | bf16x3 | bf16
     ops.TILE_TABLE = {k: v for k, v in ops.TILE_TABLE.items() if "@" in k.split(":")[0]}
+for kind in filter(None, os.environ.get("RETUNE", "").split(",")):  # RETUNE=wgrad: tune that pass afresh (new kernel variants)
+    ops.TILE_TABLE = {k: v for k, v in ops.TILE_TABLE.items() if not k.startswith(kind)}
 J = 23
 C = 6 * J + 3
 ch = [64, 128, 256, 512, 1024]
