@@ -521,3 +521,22 @@ def test_train_loop_checkpoints_and_metrics_log(golden_dir, tmp_path):
     m2, _ = build_model(cfg, ck)                                               # reference-format checkpoint loads strictly
     back = m2.state_dict()
     assert all(torch.equal(back[k].cpu(), v) for k, v in ck.items())
+
+
+@pytest.mark.gpu
+def test_device_prefetcher_yields_the_loader_batches_in_order():
+    """DevicePrefetcher == `{k: v.to(device)}` per batch (order, ragged last batch, dtypes), one batch ahead on a copy stream;
+    consumed immediately by compute on the current stream without a host sync."""
+    from scrubvae_amd.train.trainer import DevicePrefetcher
+    g = torch.Generator().manual_seed(0)
+    ds = [{"x6d": torch.randn(3, 64, 18, 6, generator=g), "ids": torch.full((3, 1), i, dtype=torch.int16)} for i in range(5)]
+    ds.append({"x6d": torch.randn(1, 64, 18, 6, generator=g), "ids": torch.full((1, 1), 5, dtype=torch.int16)})
+    sums = []
+    for i, batch in enumerate(DevicePrefetcher(ds, "cuda")):
+        assert batch["x6d"].is_cuda and batch["ids"].dtype == torch.int16
+        assert int(batch["ids"][0]) == i
+        sums.append(batch["x6d"].double().sum())           # queued on the compute stream right away
+    assert len(sums) == 6
+    for i, s in enumerate(sums):
+        assert abs(float(s) - float(ds[i]["x6d"].double().sum())) < 1e-9
+    assert [b["ids"].device.type for b in DevicePrefetcher(ds[:2], "cpu")] == ["cpu", "cpu"]
