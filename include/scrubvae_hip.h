@@ -155,7 +155,9 @@ int svae_bn_eval_coeffs(int C, const float* gamma, const float* beta, float eps,
                         const float* running_mean, const float* running_var,
                         float* scale, float* shift, void* stream);
 /* y = PReLU(x*scale+shift) with scalar slope *alpha (nn.PReLU(), residual.py:89,113,147,
- * 174,199).  scale/shift NULL => identity affine (conv_in's bare PReLU). */
+ * 174,199).  scale/shift NULL => identity affine (conv_in's bare PReLU).  alpha NULL in this and the
+ * two backward calls => tanh instead of PReLU (model.activation == "tanh", nn.Tanh() at the same
+ * lines): act'(u) = 1 - tanh(u)^2, no slope gradient (dalpha_part is written as zeros). */
 int svae_affine_prelu_fwd(const float* x, const float* scale, const float* shift, const float* alpha,
                           float* y, long long rows, int C, int ld, void* stream);
 /* backward, pass 1: partial column sums  part[n_chunks][2][C] = (sum du, sum du*xhat),

@@ -65,6 +65,7 @@ class OracleConfig:
     discrete_classes: Optional[Dict[str, torch.Tensor]] = None
     bn_eps: float = 1e-4  # residual.py:88,112,146,173
     bn_momentum: float = 0.1
+    activation: str = "prelu"  # model.activation: "tanh" puts nn.Tanh() wherever the default has nn.PReLU() (residual.py:89)
 
     @property
     def in_channels(self):  # get/model.py:33-35
@@ -142,7 +143,8 @@ def init_state_dict(cfg: OracleConfig, seed=0, dtype=torch.float32, scale=1.0):
         sd[name + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
 
     def prelu(name):
-        sd[name + ".weight"] = torch.full((1,), 0.25, dtype=dtype)
+        if cfg.activation != "tanh":  # nn.Tanh() has no parameters
+            sd[name + ".weight"] = torch.full((1,), 0.25, dtype=dtype)
 
     def lin(name, out, inp):
         sd[name + ".weight"] = rnd(out, inp, fan=inp)
@@ -212,7 +214,8 @@ def trainable_names(sd):
 
 # --------------------------------------------------------------------------- layers
 def _prelu(x, w):
-    return F.prelu(x, w)
+    """the block activation: PReLU with the given slope, or tanh when the model has none (w is None)"""
+    return torch.tanh(x) if w is None else F.prelu(x, w)
 
 
 def _bn(x, sd, name, cfg, train, new_stats):
@@ -240,9 +243,9 @@ def res_block(x, sd, p, cfg, train, new_stats):
     k = cfg.kernel
     skip = F.conv1d(x, sd[p + ".skip.weight"], sd[p + ".skip.bias"], stride=2, padding=k // 2)
     h = F.conv1d(x, sd[p + ".residual.0.weight"], sd[p + ".residual.0.bias"], stride=2, padding=k // 2)
-    h = _prelu(_bn(h, sd, p + ".residual.1", cfg, train, new_stats), sd[p + ".residual.2.weight"])
+    h = _prelu(_bn(h, sd, p + ".residual.1", cfg, train, new_stats), sd.get(p + ".residual.2.weight"))
     h = F.conv1d(h, sd[p + ".residual.3.weight"], sd[p + ".residual.3.bias"], stride=1, padding=k // 2)
-    return _prelu(_bn(h + skip, sd, p + ".add.0", cfg, train, new_stats), sd[p + ".add.1.weight"])
+    return _prelu(_bn(h + skip, sd, p + ".add.0", cfg, train, new_stats), sd.get(p + ".add.1.weight"))
 
 
 def res_block_T(x, sd, p, cfg, train, new_stats):
@@ -251,9 +254,9 @@ def res_block_T(x, sd, p, cfg, train, new_stats):
     up = F.interpolate(x, scale_factor=2, mode="linear", align_corners=False)
     skip = F.conv1d(up, sd[p + ".skip.1.weight"], sd[p + ".skip.1.bias"], stride=1, padding=k // 2)
     h = F.conv_transpose1d(x, sd[p + ".residual.0.weight"], sd[p + ".residual.0.bias"], stride=1, padding=k // 2)
-    h = _prelu(_bn(h, sd, p + ".residual.1", cfg, train, new_stats), sd[p + ".residual.2.weight"])
+    h = _prelu(_bn(h, sd, p + ".residual.1", cfg, train, new_stats), sd.get(p + ".residual.2.weight"))
     h = F.conv_transpose1d(h, sd[p + ".residual.3.weight"], sd[p + ".residual.3.bias"], stride=2, padding=k // 2)
-    return _prelu(_bn(h + skip, sd, p + ".add.0", cfg, train, new_stats), sd[p + ".add.1.weight"])
+    return _prelu(_bn(h + skip, sd, p + ".add.0", cfg, train, new_stats), sd.get(p + ".add.1.weight"))
 
 
 def normalize_root(root, arena):  # residual.py:428-431
@@ -288,7 +291,7 @@ def encode(sd, cfg, data, train, new_stats=None):
         x_in = x6d.reshape(B, W, -1)
     x = x_in.moveaxis(1, -1)
     x = _prelu(F.conv1d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=3),
-               sd["encoder.activation.weight"])
+               sd.get("encoder.activation.weight"))
     for i in range(len(cfg.channel) - 1):
         x = res_block(x, sd, f"encoder.res_layers.{i}", cfg, train, new_stats)
     flat = x.flatten(1)

@@ -185,11 +185,20 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
   shift[c] = beta[c] - rm[c] * gamma[c] * rstd;
 }
 
-// ------------------------------------------------------------- affine + PReLU forward
+// ------------------------------------------------------------- affine + PReLU (alpha != NULL) / tanh (alpha == NULL)
+// model.activation = "tanh" (residual.py:89,113,147,174,199) replaces every PReLU by nn.Tanh: same kernels, the slope
+// pointer is NULL, act(u) = tanh(u), act'(u) = 1 - tanh(u)^2 recomputed from the saved pre-activation input
+__device__ __forceinline__ float act_fwd(float u, float a, bool th) { return th ? tanhf(u) : (u > 0.f ? u : a * u); }
+__device__ __forceinline__ float act_grad(float u, float a, bool th) {
+  if (th) { const float t = tanhf(u); return 1.f - t * t; }
+  return u > 0.f ? 1.f : a;
+}
+
 __global__ __launch_bounds__(256) void affine_prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ alpha,
                                                                 float* __restrict__ y, long long rows, int C4, int ld) {
-  const float a = alpha[0];
+  const bool th = alpha == nullptr;
+  const float a = th ? 0.f : alpha[0];
   const long long total = rows * C4;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / C4;
@@ -199,8 +208,8 @@ __global__ __launch_bounds__(256) void affine_prelu_fwd_kernel(const float* __re
       const float4 s = ld4(scale + c), t = ld4(shift + c);
       v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
     }
-    v.x = v.x > 0.f ? v.x : a * v.x; v.y = v.y > 0.f ? v.y : a * v.y;
-    v.z = v.z > 0.f ? v.z : a * v.z; v.w = v.w > 0.f ? v.w : a * v.w;
+    v.x = act_fwd(v.x, a, th); v.y = act_fwd(v.y, a, th);
+    v.z = act_fwd(v.z, a, th); v.w = act_fwd(v.w, a, th);
     st4(y + r * ld + c, v);
   }
 }
@@ -217,7 +226,8 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_partial_kernel(
   const long long r0 = (long long)blockIdx.x * STAT_ROWS;
   long long r1 = r0 + STAT_ROWS;
   if (r1 > rows) r1 = rows;
-  const float a = alpha[0];
+  const bool th = alpha == nullptr;
+  const float a = th ? 0.f : alpha[0];
   float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
   float da = 0.f;
   if (c < C) {
@@ -238,8 +248,8 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_partial_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float u = xv[k] * sc[k] + sh[k];
-        const float du = u > 0.f ? dv[k] : a * dv[k];
-        if (!(u > 0.f)) da += dv[k] * u;
+        const float du = dv[k] * act_grad(u, a, th);
+        if (!th && !(u > 0.f)) da += dv[k] * u;
         s0[k] += du;
         s1[k] += du * (xv[k] - mu[k]) * rs[k];
       }
@@ -266,7 +276,8 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
     const float* __restrict__ alpha, const float* __restrict__ sums, float inv_count, float* __restrict__ dx, long long rows,
     int C, int ld) {
-  const float a = alpha[0];
+  const bool th = alpha == nullptr;
+  const float a = th ? 0.f : alpha[0];
   const int C4 = C / 4;
   const long long total = rows * C4;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_apply_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float u = xv[k] * sc[k] + sh[k];
-      const float du = u > 0.f ? dv[k] : a * dv[k];
+      const float du = dv[k] * act_grad(u, a, th);
       if (sums != nullptr) {
         const float xh = (xv[k] - mu[k]) * rs[k];
         o[k] = gm[k] * rs[k] * (du - s0[k] * inv_count - xh * s1[k] * inv_count);
@@ -699,7 +710,7 @@ extern "C" int svae_bn_eval_coeffs(int C, const float* gamma, const float* beta,
 
 extern "C" int svae_affine_prelu_fwd(const float* x, const float* scale, const float* shift, const float* alpha, float* y,
                                      long long rows, int C, int ld, void* stream) {
-  SVAE_REQUIRE(x && y && alpha && rows > 0, SVAE_ERR_ARG, "affine_prelu_fwd: null pointer");
+  SVAE_REQUIRE(x && y && rows > 0, SVAE_ERR_ARG, "affine_prelu_fwd: null pointer");
   SVAE_REQUIRE(C % 4 == 0 && ld % 4 == 0, SVAE_ERR_ALIGN, "affine_prelu_fwd: C, ld must be multiples of 4");
   hipLaunchKernelGGL(affine_prelu_fwd_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, ST(stream), x, scale, shift, alpha, y,
                      rows, C / 4, ld);
@@ -709,7 +720,7 @@ extern "C" int svae_affine_prelu_fwd(const float* x, const float* scale, const f
 extern "C" int svae_affine_prelu_bwd_partial(const float* dy, const float* x, const float* scale, const float* shift,
                                              const float* mean, const float* rstd, const float* alpha, long long rows, int C,
                                              int ld, float* part, float* dalpha_part, void* stream) {
-  SVAE_REQUIRE(dy && x && alpha && part && dalpha_part && rows > 0, SVAE_ERR_ARG, "affine_prelu_bwd_partial: null pointer");
+  SVAE_REQUIRE(dy && x && part && dalpha_part && rows > 0, SVAE_ERR_ARG, "affine_prelu_bwd_partial: null pointer");
   SVAE_REQUIRE(C % 4 == 0 && ld % 4 == 0, SVAE_ERR_ALIGN, "affine_prelu_bwd_partial: C, ld must be multiples of 4");
   hipLaunchKernelGGL(affine_prelu_bwd_partial_kernel, dim3(svae_bn_chunks(rows), (C + 63) / 64), dim3(256), 0, ST(stream), dy, x,
                      scale, shift, mean, rstd, alpha, rows, C, ld, part, dalpha_part);
@@ -721,7 +732,7 @@ extern "C" int svae_affine_prelu_bwd_apply(const float* dy, const float* x, cons
                                            const float* sums, double count, float* dx, long long rows, int C, int ld,
                                            float* dgamma, float* dbeta, float* dalpha, const float* dalpha_part, int n_chunks,
                                            int accumulate_param_grads, void* stream) {
-  SVAE_REQUIRE(dy && x && alpha && dx && rows > 0, SVAE_ERR_ARG, "affine_prelu_bwd_apply: null pointer");
+  SVAE_REQUIRE(dy && x && dx && rows > 0, SVAE_ERR_ARG, "affine_prelu_bwd_apply: null pointer");
   SVAE_REQUIRE(!sums || (mean && rstd && gamma && count > 0), SVAE_ERR_ARG, "affine_prelu_bwd_apply: BN tensors missing");
   hipLaunchKernelGGL(affine_prelu_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, ST(stream), dy, x, scale, shift,
                      mean, rstd, gamma, alpha, sums, sums ? (float)(1.0 / count) : 0.f, dx, rows, C, ld);

@@ -216,6 +216,24 @@ class BatchNormP(Leaf):
             self.num_batches_tracked.zero_()
 
 
+class TanhP(nn.Module):
+    """nn.Tanh() where the default model has a PReLU (model.activation == "tanh", residual.py:89,113,147,174,199): no
+    parameters; the activation kernels get a NULL slope pointer."""
+
+    weight = None
+
+    def extra_repr(self):
+        return "tanh"
+
+
+def make_activation(activation):
+    return TanhP() if activation == "tanh" else PReLUP()  # the reference: nn.Tanh() if activation == "tanh" else nn.PReLU()
+
+
+def slope_grad(act):
+    return None if act.weight is None else act.weight.grad
+
+
 class PReLUP(Leaf):
     """nn.PReLU() (one shared slope, init 0.25); stored in a 16-byte slot."""
 

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..ops import pad16
 from .._lib import make_tree
-from .layers import ConvP, LinearP, BatchNormP, PReLUP, Marker, Leaf
+from .layers import ConvP, LinearP, BatchNormP, PReLUP, Marker, Leaf, make_activation, slope_grad
 from .disentangle import GRScrubber, AdvNetScrubber, MLPEnsemble, EnsembleRunner
 
 
@@ -54,16 +54,14 @@ class ResidualBlock(nn.Module):
 
     def __init__(self, in_channels, out_channels, kernel=3, activation="prelu", dilation=1):
         super().__init__()
-        if activation != "prelu":
-            raise NotImplementedError("scrubvae_amd implements activation='prelu' (the reference default)")
         if dilation != 1:
             raise NotImplementedError("init_dilation is not supported by the HIP trunk yet")
         self.residual = nn.Sequential(
             ConvP(in_channels, out_channels // 2, kernel, 2, kernel // 2),
-            BatchNormP(out_channels // 2), PReLUP(),
+            BatchNormP(out_channels // 2), make_activation(activation),
             ConvP(out_channels // 2, out_channels, kernel, 1, kernel // 2))
         self.skip = ConvP(in_channels, out_channels, kernel, 2, kernel // 2)
-        self.add = nn.Sequential(BatchNormP(out_channels), PReLUP())
+        self.add = nn.Sequential(BatchNormP(out_channels), make_activation(activation))
 
 
 class ResidualBlockTranspose(nn.Module):
@@ -71,15 +69,15 @@ class ResidualBlockTranspose(nn.Module):
 
     def __init__(self, in_channels, out_channels, kernel=3, scale_factor=2, activation="prelu", dilation=1):
         super().__init__()
-        if activation != "prelu" or dilation != 1 or scale_factor != 2:
-            raise NotImplementedError("only prelu / dilation 1 / scale 2")
+        if dilation != 1 or scale_factor != 2:
+            raise NotImplementedError("only dilation 1 / scale 2")
         self.residual = nn.Sequential(
             ConvP(in_channels, in_channels // 2, kernel, 1, kernel // 2, transposed=True),
-            BatchNormP(in_channels // 2), PReLUP(),
+            BatchNormP(in_channels // 2), make_activation(activation),
             ConvP(in_channels // 2, out_channels, kernel, 2, kernel // 2, transposed=True))
         self.skip = nn.Sequential(Marker("Upsample(scale_factor=2, mode=linear)"),
                                   ConvP(in_channels, out_channels, kernel + 1, 1, kernel // 2))
-        self.add = nn.Sequential(BatchNormP(out_channels), PReLUP())
+        self.add = nn.Sequential(BatchNormP(out_channels), make_activation(activation))
 
 
 def _flat_index(C, L):
@@ -102,7 +100,7 @@ class ResidualEncoder(nn.Module):
         if init_dilation is not None:
             raise NotImplementedError("init_dilation is not supported by the HIP trunk yet")
         self.conv_in = ConvP(in_channels, ch[0], 7, 1, 3)
-        self.activation = PReLUP()
+        self.activation = make_activation(activation)
         self.res_layers = nn.Sequential(*[ResidualBlock(ch[i], ch[i + 1], kernel, activation) for i in range(len(ch) - 1)])
         self.latent_len = find_latent_dim(window, kernel, len(ch) - 1)
         flatten_dim = self.latent_len * ch[-1]
@@ -448,7 +446,7 @@ class ResVAE(nn.Module):
             gl.copy_(sums)
             self._allreduce(gl)
             ops.affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, bn.weight, act.weight, gl, rows * self.world_size,
-                                       dx, rows, Cp, Cp, None, None, act.weight.grad, dap, nch, acc)
+                                       dx, rows, Cp, Cp, None, None, slope_grad(act), dap, nch, acc)
             if acc:
                 ops.axpy(1.0, sums[0], bn.bias.grad)
                 ops.axpy(1.0, sums[1], bn.weight.grad)
@@ -456,7 +454,7 @@ class ResVAE(nn.Module):
                 bn.bias.grad.copy_(sums[0])
                 bn.weight.grad.copy_(sums[1])
         else:
-            ops.bn_bwd_reduce(part, nch, Cp, sums, bn.weight.grad, bn.bias.grad, act.weight.grad, dap, dap.numel(), acc)
+            ops.bn_bwd_reduce(part, nch, Cp, sums, bn.weight.grad, bn.bias.grad, slope_grad(act), dap, dap.numel(), acc)
             ops.affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, bn.weight, act.weight, sums, count, dx, rows, Cp, Cp,
                                        None, None, None, dap, nch, acc)
         return dx
@@ -887,7 +885,7 @@ class ResVAE(nn.Module):
         ops.affine_prelu_bwd_partial(g, c0, None, None, None, None, enc.activation.weight, rows, C0, C0, part, dap)
         g_c0 = self._buf("g.enc.c_in", (rows, C0))
         ops.affine_prelu_bwd_apply(g, c0, None, None, None, None, None, enc.activation.weight, None, 1.0, g_c0, rows, C0, C0,
-                                   None, None, enc.activation.weight.grad, dap, nch, acc)
+                                   None, None, slope_grad(enc.activation), dap, nch, acc)
         x_in = self._buf("x_in", (rows, pad16(self.in_channels)))
         cvi = self._conv("enc.conv_in", enc.conv_in, B, W)
         self._wgrad(cvi, x_in, g_c0, enc.conv_in, acc)

@@ -159,6 +159,40 @@ def test_bn_prelu_fwd_bwd(ops, rows, Cc):
     assert relerr(da.cpu(), alpha.grad) < 2e-5
 
 
+@pytest.mark.parametrize("rows,Cc", [(700, 48), (37, 16)])
+def test_bn_tanh_fwd_bwd(ops, rows, Cc):
+    """model.activation == "tanh": the same kernels with a NULL slope pointer = train-mode BatchNorm + tanh, vs torch fp64."""
+    g = torch.Generator().manual_seed(rows + 1)
+    x = (torch.randn(rows, Cc, generator=g, dtype=torch.float64) * 2 + 0.7).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(Cc, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.1 * torch.randn(Cc, generator=g, dtype=torch.float64)).requires_grad_(True)
+    rm, rv = torch.zeros(Cc, dtype=torch.float64), torch.ones(Cc, dtype=torch.float64)
+    y = torch.tanh(F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-4))
+    dy = torch.randn(rows, Cc, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    dev = lambda t: t.detach().float().cuda().contiguous()
+    xd, gd, bd, dyd = dev(x), dev(gamma), dev(beta), dev(dy)
+    nch = ops.bn_chunks(rows)
+    part, sums = torch.empty(nch, 2, Cc, device="cuda"), torch.empty(2, Cc, device="cuda")
+    rmd, rvd = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    mean, rstd, scale, shift = (torch.empty(Cc, device="cuda") for _ in range(4))
+    ops.bn_stats_partial(xd, rows, Cc, Cc, part)
+    ops.bn_reduce_partials(part, nch, Cc, sums)
+    ops.bn_finalize(sums, rows, Cc, gd, bd, 1e-4, 0.1, rmd, rvd, mean, rstd, scale, shift)
+    yd = torch.empty_like(xd)
+    ops.affine_prelu_fwd(xd, scale, shift, None, yd, rows, Cc, Cc)
+    assert relerr(yd.cpu(), y.detach()) < 5e-6
+    dap = torch.empty(nch * ((Cc + 63) // 64), device="cuda")
+    ops.affine_prelu_bwd_partial(dyd, xd, scale, shift, mean, rstd, None, rows, Cc, Cc, part, dap)
+    ops.bn_reduce_partials(part, nch, Cc, sums)
+    dxd = torch.empty_like(xd)
+    dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    ops.affine_prelu_bwd_apply(dyd, xd, scale, shift, mean, rstd, gd, None, sums, rows, dxd, rows, Cc, Cc, dg, db, None, dap, nch, False)
+    assert relerr(dxd.cpu(), x.grad) < 2e-5
+    assert relerr(dg.cpu(), gamma.grad) < 2e-5 and relerr(db.cpu(), beta.grad) < 2e-5
+    assert float(dap.abs().max()) == 0.0  # no slope, no slope-gradient partials
+
+
 def test_bare_prelu_bwd(ops):
     rows, Cc = 300, 64
     torch.manual_seed(3)

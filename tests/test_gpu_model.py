@@ -25,7 +25,7 @@ from tests.test_oracle_golden import SCENARIOS, load_fixture, rel, ARENA
 
 def build_model(cfg, sd):
     from scrubvae_amd.get import model as get_model
-    model_config = dict(type="rcnn", kernel=cfg.kernel, z_dim=cfg.z_dim, window=cfg.window, activation="prelu",
+    model_config = dict(type="rcnn", kernel=cfg.kernel, z_dim=cfg.z_dim, window=cfg.window, activation=cfg.activation,
                         diag=cfg.diag, init_dilation=None, prior="gaussian", channel=list(cfg.channel))
     dis = dict(method=cfg.method, alpha=cfg.alpha, features=cfg.features or [])
     m = get_model(model_config, None, None, dis, cfg.n_keypts, "midfwd", arena_size=cfg.arena_size,
@@ -40,7 +40,7 @@ def to_dev(data):
 
 
 @pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "rotation_tiny", "fullL_ids_tiny", "tc_tiny", "vanilla_default_B4",
-                                  "w256_tiny", "w256_6blocks_tiny", "linear_gr_tiny"])
+                                  "w256_tiny", "w256_6blocks_tiny", "linear_gr_tiny", "tanh_tiny"])
 def test_step0_matches_reference_fixture(golden_dir, name):
     from scrubvae_amd.train.losses import get_batch_loss
     fx, cfg, loss_scale, opt, sd, data = load_fixture(golden_dir, name)
@@ -422,7 +422,7 @@ def bf16x6_everywhere(request):
     ops.SPLIT_MIN_FLOPS = keep[1]
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "fullL_ids_tiny", "vanilla_default_B4", "w256_6blocks_tiny"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "fullL_ids_tiny", "vanilla_default_B4", "w256_6blocks_tiny", "tanh_tiny"])
 def test_step0_matches_reference_fixture_bf16x6(golden_dir, name, bf16x6_everywhere):
     """The reference fixtures at the SAME fp32 tolerances with the contractions on the bf16 matrix cores
     (bench.py's default precision): the 3-piece split is fp32-accurate, not a reduced-precision mode."""

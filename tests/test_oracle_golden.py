@@ -42,6 +42,7 @@ SCENARIOS = {
                                       features=["avg_speed_3d", "heading"], **TINY),
                        {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_lin": 0.6, "heading_lin": 1.5,
                         "avg_speed_3d_gr": 1.0, "heading_gr": 2.0}, "adamw"),
+    "tanh_tiny": (O.OracleConfig(diag=True, activation="tanh", **TINY), {"jpe": 1.0, "root": 1.0, "prior": 0.5}, "adamw"),
     # BASELINE config 5's shape: window 256; four blocks = the unmodified reference, six blocks = the
     # reference with only its default dilation list lengthened (it cannot build >4 blocks otherwise,
     # see make_fixtures.py)
