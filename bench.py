@@ -167,6 +167,11 @@ def pmc_traffic(kernel):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): whatever libraries print while the job runs (RCCL's version banner,
+    # gloo's connection messages, ...) is sent to stderr instead -- file descriptor 1 is pointed at stderr until the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     from scrubvae_amd import parallel, ops
     from scrubvae_amd.train.losses import get_batch_loss
     from scrubvae_amd.train.trainer import FusedAdam, clip_grad_norm_
@@ -316,7 +321,8 @@ def main():
                                        for k, v in sorted(probe.summary().items())}}
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, method, feats, loss)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
