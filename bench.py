@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
-PRODUCTS = {"f32": 1, "bf16x6": 6, "bf16x6w3": 6, "bf16x3": 3, "bf16": 1}  # matrix-core products per algorithmic multiply (fwd / dgrad)
+PRODUCTS = {"f32": 1, "bf16x6": 6, "bf16x6w3": 6, "bf16x6b3": 6, "bf16x3": 3, "bf16": 1}  # matrix-core products per algorithmic multiply (fwd / dgrad)
 
 
 def parse():
@@ -52,10 +52,11 @@ def parse():
                          "torch DistributedDataParallel around the reference model")
     ap.add_argument("--local-bn", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph (single GPU)")
-    ap.add_argument("--precision", default=os.environ.get("SVAE_PRECISION", "bf16x6w3"), choices=list(PRODUCTS),
+    ap.add_argument("--precision", default=os.environ.get("SVAE_PRECISION", "bf16x6b3"), choices=list(PRODUCTS),
                     help="arithmetic of the large contractions: f32 = fp32 MFMA; bf16x6 = fp32-accurate 3-piece split on the bf16 "
                          "matrix cores (6 products); bf16x6w3 = the same with 2 pieces / 3 products for the weight-gradient "
-                         "contractions (gradient error vs fp64 unchanged, DESIGN.md 4); bf16x3 / bf16 = 2 / 1 pieces everywhere "
+                         "contractions (gradient error vs fp64 unchanged, DESIGN.md 4); bf16x6b3 = 3 products for the whole "
+                         "backward pass, 6 for the forward; bf16x3 / bf16 = 2 / 1 pieces everywhere "
                          "(reduced accuracy, study only)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="timed region without the concurrent side streams (what the roofline region always uses)")
@@ -286,7 +287,10 @@ def main():
                                      f"bf16 pieces and runs {PRODUCTS[args.precision]} cross product(s) on v_mfma_f32_32x32x16_bf16"
                                      + (" (fp32-accurate, DESIGN.md 4)" if args.precision == "bf16x6" else
                                         " forward and data-gradient (fp32-accurate), 3 (2 pieces) for the weight-gradient contractions "
-                                        "(gradient error vs fp64 unchanged, DESIGN.md 4)" if args.precision == "bf16x6w3" else " (reduced accuracy)")),
+                                        "(gradient error vs fp64 unchanged, DESIGN.md 4)" if args.precision == "bf16x6w3" else
+                                        " forward (outputs, losses, ELBO: fp32-accurate), 3 (2 pieces) for the data- and weight-gradient "
+                                        "contractions (gradient error vs fp64 within the fp32 path's own, DESIGN.md 4)"
+                                        if args.precision == "bf16x6b3" else " (reduced accuracy)")),
                        "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("+syncbn" if args.sync_bn else "+localbn")),
                        "final_total_loss": total_loss},
@@ -298,7 +302,11 @@ def main():
                 kname, s = max(summ.items(), key=lambda kv: kv[1]["ms"])
                 tf = s["flops"] / (s["ms"] * 1e-3) / 1e12
                 split_kernel = "bf16s" in kname
-                peak = PEAK_BF16_MFMA_TFLOPS / PRODUCTS[args.precision] if split_kernel else PEAK_F32_MFMA_TFLOPS
+                # products per algorithmic multiply of THIS template: its piece count is the third template argument
+                import re
+                pm = re.search(r"bf16s\w*<\d+, \d+, (\d)", kname)
+                k_products = {3: 6, 2: 3, 1: 1}[int(pm.group(1))] if pm else PRODUCTS[args.precision]
+                peak = PEAK_BF16_MFMA_TFLOPS / k_products if split_kernel else PEAK_F32_MFMA_TFLOPS
                 out["roofline"] = {"measured": f"second timed region of {args.steps} steps with the side HIP streams serialised "
                                                f"({dt_serial / args.steps * 1e3:.3f} ms/step; the headline region overlaps kernels "
                                                "on 3 streams, where a launch's duration is not the kernel's own time); "
@@ -308,7 +316,7 @@ def main():
                                    # the committed PMC passes are of the default command (configs[1], batch 1024)
                                    "traffic": pmc_traffic("svae::" + kname) if (args.channel_list == CHANNELS and args.window == 64 and B == 1024
                                                                                 and not args.full) else None,
-                                   "peak_note": (f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {PRODUCTS[args.precision]} "
+                                   "peak_note": (f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {k_products} "
                                                  "matrix-core products per algorithmic multiply (achieved counts algorithmic FLOPs)"
                                                  if split_kernel else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                                    "kernel": "svae::" + kname,

@@ -1178,10 +1178,15 @@ static int halo_rows(const GatherArgs& g, int bm) {
 
 template <int BN>
 static int launch_halo(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
-  if (pieces != 3) { set_error("split gather: the halo kernel is built for 3 pieces only"); return SVAE_ERR_ARG; }
-  if (rows <= 160) hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 3, 4, 2, 160>), grid, dim3(512), 0, st, sa);
-  else if (rows <= 264) hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 3, 4, 2, 264>), grid, dim3(512), 0, st, sa);
-  else { set_error("split gather: halo image of %d rows does not fit", rows); return SVAE_ERR_ARG; }
+  if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_ARG; }
+  if (rows > 264) { set_error("split gather: halo image of %d rows does not fit", rows); return SVAE_ERR_ARG; }
+  if (pieces == 3) {
+    if (rows <= 160) hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 3, 4, 2, 160>), grid, dim3(512), 0, st, sa);
+    else hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 3, 4, 2, 264>), grid, dim3(512), 0, st, sa);
+  } else {
+    if (rows <= 160) hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 2, 4, 2, 160>), grid, dim3(512), 0, st, sa);
+    else hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 2, 4, 2, 264>), grid, dim3(512), 0, st, sa);
+  }
   return SVAE_OK;
 }
 

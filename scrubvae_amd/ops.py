@@ -94,12 +94,18 @@ _KIND_ID = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 # is as accurate as f32.  Read when a Conv is constructed; convs below SPLIT_MIN_FLOPS stay f32.
 # The library default is "f32" (or $SVAE_PRECISION); bench.py selects "bf16x6w3".
 PRECISION = os.environ.get("SVAE_PRECISION", "f32")
-_PIECES = {"f32": 0, "bf16x6": 3, "bf16x6w3": 3, "bf16x3": 2, "bf16": 1}
+_PIECES = {"f32": 0, "bf16x6": 3, "bf16x6w3": 3, "bf16x6b3": 3, "bf16x3": 2, "bf16": 1}
 # "bf16x6w3": forward / data-gradient contractions with 3 pieces (6 products), WEIGHT-gradient contractions with 2
 # pieces (3 products).  A weight gradient sums >= thousands of rows; its own 2^-16-per-product rounding is invisible
 # next to the error the forward / data-gradient arithmetic already leaves on the same tensor
 # (tests/studies/precision_bf16_split.py: worst gradient error vs fp64 identical to bf16x6, 3-7x below fp32's own).
-_WGRAD_PIECES = {"bf16x6w3": 2}
+_WGRAD_PIECES = {"bf16x6w3": 2, "bf16x6b3": 2}
+# "bf16x6b3": the whole BACKWARD pass (data- and weight-gradient contractions) with 2 pieces / 3 products, the forward
+# (outputs, every loss term, the ELBO) with 3 pieces / 6 products.  Same study, row `x6+b:x3`: worst gradient error vs
+# fp64 1.2e-3 / 4.8e-4 / 3.4e-4 / 2.2e-2 on the four fixtures against 8.3e-4 / 3.1e-3 / 3.4e-4 / 2.1e-2 for six products
+# everywhere and 5.6e-3 / 4.4e-3 / 9.2e-4 / 6.7e-2 for the reference's own fp32 arithmetic.  The data-gradient kernels read
+# the two leading planes of the 3-piece weight split (second piece truncated instead of rounded: a 2^-17 relative bias).
+_DGRAD_PIECES = {"bf16x6b3": 2}
 SPLIT_MIN_FLOPS = float(os.environ.get("SVAE_SPLIT_MIN_FLOPS", 2e9))
 # split gather kernels, code VBBBNNN: V = 0: 4 waves, double-buffered LDS; 1: 4 waves, one LDS buffer; 2 / 3: 8 waves
 # (BM = 128), one / two buffers; 4 / 5: wave-specialised (4 producer + 8 / 4 consumer waves), 2 tiles in flight;
@@ -181,6 +187,7 @@ class Conv:
         self.pieces = (_PIECES[PRECISION] if self.flops >= SPLIT_MIN_FLOPS else 0) if pieces is None else int(pieces)
         # pieces of the weight-gradient contraction (differs from self.pieces only in the "bf16x6w3" precision)
         self.wgrad_pieces = (_WGRAD_PIECES.get(PRECISION, self.pieces) if self.pieces else 0) if pieces is None else int(pieces)
+        self.dgrad_pieces = (_DGRAD_PIECES.get(PRECISION, self.pieces) if self.pieces else 0) if pieces is None else int(pieces)
         self._wsplit, self._split_epoch, self._split_src = None, -1, None
 
     def split_weights(self, w):
@@ -196,7 +203,7 @@ class Conv:
     _F32_FLAG = 100000000  # table / log encoding: "this kind of this split-precision conv runs the fp32 kernel <code % flag>"
 
     def _base_pieces(self, kind):
-        return self.wgrad_pieces if kind == "wgrad" else self.pieces
+        return self.wgrad_pieces if kind == "wgrad" else (self.dgrad_pieces if kind == "dgrad" else self.pieces)
 
     def _kind_pieces(self, kind):
         return self.__dict__.get("_kp", {}).get(kind, self._base_pieces(kind))
@@ -226,7 +233,7 @@ class Conv:
         cands = []
         if base:
             cands += [(base, c) for c in (_SPLIT_WGRAD_CODES if kind == "wgrad" else _SPLIT_GATHER_CODES)]
-        if not base or (MIX_F32 and (base == 3 or (kind == "wgrad" and self.pieces == 3))):
+        if not base or (MIX_F32 and (base == 3 or (kind in ("wgrad", "dgrad") and self.pieces == 3))):
             cands += [(0, c) for c in (_WGRAD_CODES if kind == "wgrad" else _GATHER_CODES)]
         best, best_t = (base, 0), float("inf")
         for pieces, code in cands:

@@ -15,7 +15,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from oracle import scvae_oracle as O  # noqa: E402
 from tests.test_oracle_golden import load_fixture, rel  # noqa: E402
 
-MODE = {"pieces": 2, "products": 3, "wgrad": None}  # wgrad: optional (pieces, products) for the weight-gradient contractions only
+# wgrad / dgrad: optional (pieces, products) for the weight-gradient / data-gradient contractions only
+MODE = {"pieces": 2, "products": 3, "wgrad": None, "dgrad": None}
 
 
 def split(x, n):
@@ -33,10 +34,12 @@ def pairs():
     return order[:p]
 
 
-def contract(fn, a, b, wgrad=False):
+def contract(fn, a, b, wgrad=False, dgrad=False):
     pieces, products = MODE["pieces"], MODE["products"]
     if wgrad and MODE["wgrad"] is not None:
         pieces, products = MODE["wgrad"]
+    if dgrad and MODE["dgrad"] is not None:
+        pieces, products = MODE["dgrad"]
     if pieces == 0:
         return fn(a, b)
     A, B = split(a, pieces), split(b, pieces)
@@ -74,7 +77,7 @@ class Conv(torch.autograd.Function):
                 y = f(xx, ww, None, stride=stride, padding=padding)
             return torch.autograd.grad(y, ww, gg)[0]
 
-        return contract(dx, g, w), contract(dw, g, x, wgrad=True), None, None, None
+        return contract(dx, g, w, dgrad=True), contract(dw, g, x, wgrad=True), None, None, None
 
 
 class Lin(torch.autograd.Function):
@@ -86,7 +89,7 @@ class Lin(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        return contract(lambda a, b: a @ b, g, w), contract(lambda a, b: a.t() @ b, g, x, wgrad=True)
+        return contract(lambda a, b: a @ b, g, w, dgrad=True), contract(lambda a, b: a.t() @ b, g, x, wgrad=True)
 
 
 _c1, _ct, _li = F.conv1d, F.conv_transpose1d, F.linear
@@ -135,9 +138,11 @@ def run(name, golden):
     ref = O.train_step(sd64, cfg64, d64, loss_scale, eps.double(), adv_perm=advp, lr=1e-4, optimizer=opt)
     rows = []
     for label, mode in (("fp32", (0, 0)), ("bf16x1", (1, 1)), ("bf16x3", (2, 3)), ("bf16x4", (2, 4)), ("bf16x6", (3, 6)),
-                        ("x6+w:x3", (3, 6, (2, 3))), ("x6+w:x1", (3, 6, (1, 1)))):
+                        ("x6+w:x3", (3, 6, (2, 3))), ("x6+w:x1", (3, 6, (1, 1))), ("x6+b:x3", (3, 6, (2, 3), (2, 3))),
+                        ("x6+b:x4", (3, 6, (2, 3), (2, 4)))):
         MODE["pieces"], MODE["products"] = mode[:2]
         MODE["wgrad"] = mode[2] if len(mode) > 2 else None
+        MODE["dgrad"] = mode[3] if len(mode) > 3 else None
         if mode[0] == 0:
             got = base
         else:

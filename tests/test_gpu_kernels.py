@@ -422,8 +422,8 @@ def _split_cases():
                      4128128, 4128064, 4064128, 5128128, 5128064, 5064128, 5064064,
                      6128128, 6128064, 6064128, 7128128, 7128064, 7064128, 7064064, 8128128, 8128064, 0):
             out.append((case, code, 3))
-        out.append((case, 64064, 2))
-        out.append((case, 2128064, 2))
+        for code in (64064, 2128064, 3128128, 4128128, 5064064, 8128128, 8128064):  # 2 pieces: the backward pass of bf16x6b3
+            out.append((case, code, 2))
         out.append((case, 1128064, 1))
     return out
 

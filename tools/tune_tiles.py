@@ -12,7 +12,7 @@ table = dict(ops.TILE_TABLE) if "--keep" in sys.argv else {}
 sys.argv = [a for a in sys.argv if a != "--keep"]
 ops.TILE_TABLE = {}
 ops.AUTOTUNE_REPS = 12
-PRECISIONS = sys.argv[1:] or ["f32", "bf16x6", "bf16x6w3"]
+PRECISIONS = sys.argv[1:] or ["f32", "bf16x6", "bf16x6w3", "bf16x6b3"]
 for prec, joints, batch, full in [(p, *c) for p in PRECISIONS
                                   for c in ((23, 1024, False), (23, 1024, True), (23, 4096, False), (18, 1024, False), (23, 256, False))]:
     ops.set_precision(prec)
