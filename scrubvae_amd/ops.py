@@ -92,7 +92,7 @@ _KIND_ID = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 # "bf16": every fp32 operand is split into 3 / 2 / 1 bf16 pieces and the 6 / 3 / 1 leading cross
 # products run on the bf16 matrix cores with fp32 accumulation (csrc/gemm_bf16s.hip); bf16x6
 # is as accurate as f32.  Read when a Conv is constructed; convs below SPLIT_MIN_FLOPS stay f32.
-# The library default is "f32" (or $SVAE_PRECISION); bench.py selects "bf16x6w3".
+# The library default is "f32" (or $SVAE_PRECISION); bench.py selects "bf16x6b3".
 PRECISION = os.environ.get("SVAE_PRECISION", "f32")
 _PIECES = {"f32": 0, "bf16x6": 3, "bf16x6w3": 3, "bf16x6b3": 3, "bf16x3": 2, "bf16": 1}
 # "bf16x6w3": forward / data-gradient contractions with 3 pieces (6 products), WEIGHT-gradient contractions with 2
