@@ -224,10 +224,13 @@ class ResVAE(nn.Module):
         self._dec_span = (min(a for a, _ in dec), max(b for _, b in dec))
         # start offsets of the encoder blocks (module order == flat order): the reverse schedule finishes block i last of
         # everything at or above _enc_cuts[i], so [cut_i, previous cut) can be all-reduced while blocks < i still run
-        self._enc_cuts = []
+        self._enc_cuts, self._enc_mid_cuts = [], []
         for blk in self.encoder.res_layers:
             ids = {id(m) for m in blk.modules()}
             self._enc_cuts.append(min(off for m, pname, shape, off, numel in slots if id(m) in ids))
+            # inside a block the order is residual.0-3, skip, add.0-1: everything from residual.3 on is final as soon as the
+            # second BatchNorm's backward and the two weight gradients that read its output gradient are queued
+            self._enc_mid_cuts.append(min(off for m, pname, shape, off, numel in slots if m is blk.residual[3]))
         self.to(device)  # buffers
         self._assign_grad_views()
 
@@ -861,6 +864,10 @@ class ResVAE(nn.Module):
             r0a = self._buf(t + ".r0a", (B * Lo, cv0.c_out_p))
             self._wgrad(cvs, a_in, g_s, blk.skip, acc)
             self._wgrad(cv3, r0a, g_s, conv3, acc)
+            if self.world_size > 1 and (enc_cut - self._enc_mid_cuts[i]) * 4 >= self.bucket_min_bytes:
+                # data-parallel: second conv, skip conv and the closing BatchNorm / PReLU of this block are final
+                works.append(self._bucket_allreduce(self._enc_mid_cuts[i], enc_cut, acc))
+                enc_cut = self._enc_mid_cuts[i]
             g_a = self._buf("g." + t + ".in", (B * L, cv0.c_in_p))
             self._fork(lambda cvs=cvs, g_s=g_s, g_a=g_a, w=blk.skip.weight: cvs.dgrad(g_s, w, g_a), k=1)
             g_r0a = self._buf("g." + t + ".r0a", (B * Lo, cv0.c_out_p))
