@@ -586,3 +586,59 @@ def test_training_trajectory_is_precision_independent(golden_dir):
     for precision in ("bf16x6w3", "bf16x6b3"):
         assert dev[precision] < 2.0 * dev["bf16x6"] + 2e-3, dev
     assert dev["bf16x6"] < 3e-2, dev
+
+
+# ------------------------------------------------------------------ shapes off the beaten path
+_ODD = {
+    # name: (B, window, joints, z, channels, kernel, diag, tree)
+    "B1_squeeze":      (1, 64, 18, 8, (8, 8, 16, 16, 32), 5, True, None),          # reference `.squeeze()` quirk at B=1 (residual.py:316)
+    "B7_w48_z5":       (7, 48, 18, 5, (8, 8, 16, 16, 32), 5, True, None),          # nothing a multiple of anything
+    "w100_odd_ch":     (3, 100, 18, 12, (12, 20, 36, 52, 68), 5, True, None),      # channel counts that are not multiples of 16
+    "w128_k3":         (4, 128, 18, 8, (8, 16, 16, 32, 32), 3, False, None),       # kernel 3, full Cholesky
+    "w64_k7_3blocks":  (5, 64, 18, 6, (16, 16, 32, 32), 7, True, None),            # kernel 7, three blocks
+    "one_chain_J5":    (6, 32, 5, 4, (8, 8, 16, 16), 5, True, [[0, 1, 2, 3, 4]]),  # a single chain, short window
+    "two_chains_J7":   (2, 64, 7, 8, (8, 8, 16, 16, 32), 5, True, [[0, 1, 2, 3], [0, 4, 5, 6]]),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(_ODD))
+@pytest.mark.parametrize("precision", ["f32", "bf16x6b3"])
+def test_odd_shapes_vs_oracle(name, precision):
+    """Shapes none of the reference fixtures cover (batch 1, ragged sizes, channel counts that need padding, other kernel
+    widths / depths / trees): one training step of the HIP model against the CPU oracle on seeded inputs."""
+    from scrubvae_amd import ops
+    from scrubvae_amd.train.losses import get_batch_loss
+    B, W, J, z, ch, k, diag, tree = _ODD[name]
+    cfg = O.OracleConfig(n_keypts=J, window=W, z_dim=z, kernel=k, channel=ch, diag=diag, arena_size=ARENA,
+                         kinematic_tree=tree or O.skeleton_tree(J))
+    sd = O.init_state_dict(cfg, seed=21)
+    data = O.synth_batch(cfg, B, seed=22)
+    eps = torch.randn(B, z, generator=torch.Generator().manual_seed(23))
+    ls = {"jpe": 1.0, "root": 1.0, "prior": 0.7}
+    # (B=1: VAE.sampling's .squeeze(), residual.py:316, drops the batch dimension of z; the comparison below flattens)
+    bl_o, g_o, _, out_o = O.train_step(sd, cfg, data, ls, eps)
+    keep = (ops.PRECISION, ops.SPLIT_MIN_FLOPS)
+    ops.set_precision(precision)
+    ops.SPLIT_MIN_FLOPS = 0.0
+    try:
+        model, dis = build_model(cfg, sd)
+        model.train()
+        d = to_dev(data)
+        d["eps"] = eps.cuda()
+        data_o = model(d)
+        bl = get_batch_loss(model, d, data_o, ls, dis)
+        bl["total"].backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(keep[0])
+        ops.SPLIT_MIN_FLOPS = keep[1]
+    for kk in ("mu", "x6d", "root"):
+        assert rel(data_o[kk].cpu().reshape(-1), out_o[kk].detach().reshape(-1)) < 5e-5, kk
+    for kk in bl_o:
+        assert rel(bl[kk].detach().cpu(), bl_o[kk]) < 1e-4, kk
+    grads = {kk: v.cpu() for kk, v in model.grads_state_dict().items()}
+    gmax = max(float(g.abs().max()) for g in g_o.values())
+    for n, g in g_o.items():
+        dd = float((grads[n] - g).abs().max()) / (float(g.abs().max()) + 1e-3 * gmax)
+        assert dd < 5e-2, (n, dd)
