@@ -642,3 +642,35 @@ def test_odd_shapes_vs_oracle(name, precision):
     for n, g in g_o.items():
         dd = float((grads[n] - g).abs().max()) / (float(g.abs().max()) + 1e-3 * gmax)
         assert dd < 5e-2, (n, dd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 5])
+def test_full_scvae_odd_batch_vs_oracle(B):
+    """configs[2]'s heads (conditional + gradient reversal incl. the ids classifier + adversarial net) at batch sizes the
+    fixtures do not have, against the oracle with the shuffle permutation injected."""
+    from scrubvae_amd.train.losses import get_batch_loss
+    feats = ["avg_speed_3d", "heading", "ids"]
+    cfg = O.OracleConfig(n_keypts=18, window=64, z_dim=8, kernel=5, channel=(8, 8, 16, 16, 32), diag=True, arena_size=ARENA,
+                         method={"conditional": feats, "grad_reversal": feats, "adversarial_net": ["heading"]}, features=feats,
+                         discrete_classes={"ids": torch.arange(4)})
+    sd = O.init_state_dict(cfg, seed=31)
+    data = O.synth_batch(cfg, B, seed=32)
+    g = torch.Generator().manual_seed(33)
+    eps, perm = torch.randn(B, 8, generator=g), torch.randperm(B, generator=g)
+    ls = {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_gr": 1.0, "heading_gr": 2.0, "ids_gr": 0.5, "heading_an": 0.5}
+    bl_o, g_o, _, out_o = O.train_step(sd, cfg, data, ls, eps, adv_perm={"heading": perm})
+    model, dis = build_model(cfg, sd)
+    model.train()
+    d = to_dev(data)
+    d["eps"] = eps.cuda()
+    data_o = model(d)
+    bl = get_batch_loss(model, d, data_o, ls, dis, adv_perm={"heading": perm})
+    bl["total"].backward()
+    for kk in bl_o:
+        assert rel(bl[kk].detach().cpu(), bl_o[kk]) < 1e-4, kk
+    grads = {kk: v.cpu() for kk, v in model.grads_state_dict().items()}
+    gmax = max(float(x.abs().max()) for x in g_o.values())
+    for n, x in g_o.items():
+        dd = float((grads[n] - x).abs().max()) / (float(x.abs().max()) + 1e-3 * gmax)
+        assert dd < 5e-2, (n, dd)
