@@ -921,9 +921,14 @@ __device__ __attribute__((aligned(16))) float wgrad_zero_row[4] = {0.f, 0.f, 0.f
 
 // NSTAGE = 2: double-buffered LDS, one barrier per stage;  NSTAGE = 1: one buffer, two barriers, half the LDS
 // (more workgroups per CU overlap each other's conversion / LDS / MFMA phases)
-template <int BM, int BN, int P, int NSTAGE>
-__global__ __launch_bounds__(256, 2) void wgrad_gemm_bf16s_kernel(const WgradArgs g) {
-  constexpr int WM = BM / 2, MT = WM / 32, WN = BN / 2, NT = WN / 32;
+// WR x WC waves (default 2 x 2 = 256 threads; the 256-row / 256-column tiles run 8 waves).  Both operands are fp32 in HBM
+// and every 16-row stage loads (BM + BN) * 64 B through the CU's vector-memory path, the resource this kernel is bound by
+// (DESIGN.md 4): a 256 x 256 tile moves half the bytes per FLOP of a 128 x 128 one, and the split over reduction rows
+// (slabs) supplies the parallelism that the larger tile takes away.
+template <int BM, int BN, int P, int NSTAGE, int WR = 2, int WC = 2>
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gemm_bf16s_kernel(const WgradArgs g) {
+  constexpr int WM = BM / WR, MT = WM / 32, WN = BN / WC, NT = WN / 32;
+  static_assert(BM + BN <= 64 * WR * WC, "one staging unit (4 rows x 4 channels) per thread");
   // channel row c of an operand image starts at c * 48 + (c / 16) * 16 bytes: the extra 16 B per 16 channels keep the
   // staging writes of a 16-lane group (8 channel quads x 2 row groups, see below) on 32 different banks
   constexpr int A_PIECE = BM * WROWB + BM, B_PIECE = BN * WROWB + BN;
@@ -1025,7 +1030,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_bf16s_kernel(const WgradArg
   };
 
   const int wave = tid >> 6, lane = tid & 63;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
   const int lr = lane & 31, h = lane >> 5;
 
   f32x16 acc[MT][NT];
@@ -1110,6 +1115,16 @@ static void launch_wgrad_p(const WgradArgs& g, dim3 grid, hipStream_t st, int pi
   else hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 1, NSTAGE>), grid, dim3(256), 0, st, g);
 }
 
+// 8-wave tiles with a 256 edge (2 or 3 pieces; LDS: 2 pieces 50 / 38 KB per stage for 256x256 / 256x128, 3 pieces 75 / 56 KB)
+// (16 waves of 64 x 64 on the 256 x 256 tile measured no better than these 8: 174 vs 164 us on the largest layer)
+template <int BM, int BN, int NSTAGE, int WR, int WC>
+static int launch_wgrad_big(const WgradArgs& g, dim3 grid, hipStream_t st, int pieces) {
+  if (pieces == 2) hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 2, NSTAGE, WR, WC>), grid, dim3(64 * WR * WC), 0, st, g);
+  else if (pieces == 3 && NSTAGE == 1) hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 3, 1, WR, WC>), grid, dim3(64 * WR * WC), 0, st, g);
+  else { set_error("wgrad split: the 256-edge tiles are built for 2 pieces (3 pieces: single LDS buffer only)"); return SVAE_ERR_ARG; }
+  return SVAE_OK;
+}
+
 // variant 0: double-buffered LDS; 1: single LDS buffer
 int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int pieces, int variant) {
 #define SVAE_WG_CASE(BM_, BN_)                                            \
@@ -1119,6 +1134,14 @@ int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, in
   }
   SVAE_WG_CASE(128, 128) else SVAE_WG_CASE(128, 64) else SVAE_WG_CASE(64, 128) else SVAE_WG_CASE(64, 64)
 #undef SVAE_WG_CASE
+#define SVAE_WG_BIG(BM_, BN_, WR_, WC_)                                                                   \
+  else if (bm == BM_ && bn == BN_) {                                                                      \
+    if (int e = (variant == 1 ? launch_wgrad_big<BM_, BN_, 1, WR_, WC_>(g, grid, st, pieces)              \
+                              : launch_wgrad_big<BM_, BN_, 2, WR_, WC_>(g, grid, st, pieces))) return e;  \
+  }
+  SVAE_WG_BIG(256, 256, 2, 4) SVAE_WG_BIG(256, 128, 4, 2) SVAE_WG_BIG(128, 256, 2, 4)
+#undef SVAE_WG_BIG
+  else { set_error("wgrad split: tile %dx%d unsupported", bm, bn); return SVAE_ERR_ARG; }
   return check_launch("wgrad_gemm_bf16s");
 }
 

@@ -1045,7 +1045,13 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
   w.ctiles = (d->c_in + w.bm - 1) / w.bm;
   long long tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
   Tile ov;
-  if (decode_tile(d->tile[2], ov)) {
+  const int tcode = d->tile[2] > 0 ? d->tile[2] % 1000000 : 0;
+  const bool big = tcode == 256256 || tcode == 256128 || tcode == 128256;  // 8-wave split-bf16 tiles (gemm_bf16s.hip)
+  if (big) {
+    w.bm = tcode / 1000; w.bn = tcode % 1000;
+    w.ctiles = (d->c_in + w.bm - 1) / w.bm;
+    tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
+  } else if (decode_tile(d->tile[2], ov)) {
     w.bm = ov.bm; w.bn = ov.bn;
     w.ctiles = (d->c_in + w.bm - 1) / w.bm;
     tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
@@ -1055,7 +1061,7 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
     tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
   }
   // resident blocks: 3 per CU for the 128x128 tile (144 VGPR+AGPR), 4 for the smaller ones
-  const long long slots = 256 * ((w.bm == 128 && w.bn == 128) ? 3 : 4);
+  const long long slots = big ? 256 : 256 * ((w.bm == 128 && w.bn == 128) ? 3 : 4);  // 8-wave tiles: one workgroup per CU
   long long want = tiles >= slots ? 1 : slots / tiles;
   const long long maxs = (w.R + 127) / 128;  // at least 128 reduction rows per split
   if (want > maxs) want = maxs;
@@ -1108,6 +1114,8 @@ static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float*
   float* slab = (float*)ws;
   if (nsplit > 1) { g.out = slab; g.slab_stride = wsize; g.accumulate = 0; }
   else { g.out = dw; g.slab_stride = 0; g.accumulate = accumulate; }
+  SVAE_REQUIRE(pieces > 0 || (wg.bm <= 128 && wg.bn <= 128), SVAE_ERR_ARG, "conv_wgrad: tile %dx%d exists for the split-bf16 kernel only",
+               wg.bm, wg.bn);
   if (pieces > 0) {
     dim3 grid(d->kernel * g.ctiles, (d->c_out + wg.bn - 1) / wg.bn, nsplit);
     if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces, d->tile[2] / 1000000)) return e;

@@ -74,7 +74,7 @@ AUTOTUNE_MIN_FLOPS = 2e8
 AUTOTUNE_REPS = 4
 # Tile choices measured once on an MI355X (tools/tune_tiles.py) for the benchmark geometries;
 # geometries not in the table are tuned on first use.
-_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_tiles.json")
+_TABLE_PATH = os.environ.get("SVAE_TILE_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_tiles.json")  # env: tuning experiments
 try:
     with open(_TABLE_PATH) as _f:
         TILE_TABLE = json.load(_f)
@@ -114,7 +114,9 @@ _SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2
                        + (4128128, 4128064, 4064128) + tuple(5000000 + c for c in _TILES)
                        + (6128128, 6128064, 6064128) + tuple(7000000 + c for c in _TILES) + (8128128, 8128064))
 _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2, 1"}
-_SPLIT_WGRAD_CODES = _TILES + tuple(1000000 + c for c in _TILES)  # 1BBBNNN: single LDS buffer
+# 1BBBNNN: single LDS buffer; 256-edge tiles: 8 waves, half the operand bytes per FLOP through the vector-memory path
+_WGRAD_BIG = (256256, 256128, 128256)
+_SPLIT_WGRAD_CODES = _TILES + tuple(1000000 + c for c in _TILES) + _WGRAD_BIG + tuple(1000000 + c for c in _WGRAD_BIG)
 MIX_F32 = True  # a bf16x6 conv may keep the fp32 MFMA kernel for a pass where that is faster (same accuracy)
 WEIGHT_EPOCH = 0  # bumped whenever master weights may have changed (start of every model pass)
 
@@ -263,7 +265,8 @@ class Conv:
             check(_lib.lib().svae_conv_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn)), "conv_tile")
             kp = self._kind_pieces(kind)
             if kp and kind == "wgrad":
-                names[kind] = f"wgrad_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}, {1 if self.desc.tile[2] >= 1000000 else 2}>"
+                waves = {256256: "2, 4", 256128: "4, 2", 128256: "2, 4"}.get(self.desc.tile[2] % 1000000, "2, 2")
+                names[kind] = f"wgrad_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}, {1 if self.desc.tile[2] >= 1000000 else 2}, {waves}>"
             elif kp:
                 v, rm = C.c_int(), C.c_int()
                 check(_lib.lib().svae_conv_split_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn), C.byref(v),
