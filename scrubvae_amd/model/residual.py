@@ -224,6 +224,9 @@ class ResVAE(nn.Module):
         self._dec_span = (min(a for a, _ in dec), max(b for _, b in dec))
         # start offsets of the encoder blocks (module order == flat order): the reverse schedule finishes block i last of
         # everything at or above _enc_cuts[i], so [cut_i, previous cut) can be all-reduced while blocks < i still run
+        enc_ids = {id(m) for m in self.encoder.modules()}
+        enc_hi = max(off + numel for m, pname, shape, off, numel in slots if id(m) in enc_ids)
+        assert enc_hi <= self._dec_span[0], "gradient buckets assume the encoder's parameters precede the decoder's in the flat buffer"
         self._enc_cuts, self._enc_mid_cuts = [], []
         for blk in self.encoder.res_layers:
             ids = {id(m) for m in blk.modules()}
