@@ -53,7 +53,7 @@ def inv_kin_windows(pose, kinematic_tree, offset, direction_process="midfwd", wa
     offsets = torch.empty(N, W, J, 3, device=pose.device) if want_offsets else None
     root = torch.empty(N, W, 3, device=pose.device) if want_root else None
     heading = torch.empty(N, 2, device=pose.device)
-    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    p = lambda t: None if t is None else t.data_ptr()
     check(_lib.lib().svae_inv_kin(p(pose), uo, C.byref(_lib.make_tree(J, kinematic_tree)), W, int(direction_process == "midfwd"),
                                   int(direction_process in ("midfwd", "x360")), truncate, p(x6d), p(offsets), p(root), p(heading),
                                   N * W, _stream()), "inv_kin")
@@ -66,8 +66,8 @@ def get_speed_parts(pose, parts=SPEED_PARTS):
     pose = pose.contiguous().float()
     flat = [j for part in parts for j in part]
     out = torch.empty(N, 3, device=pose.device)
-    check(_lib.lib().svae_speed_parts(C.c_void_p(pose.data_ptr()), (C.c_int * len(flat))(*flat), (C.c_int * len(parts))(*[len(q) for q in parts]),
-                                      len(parts), W, J, C.c_void_p(out.data_ptr()), N, _stream()), "speed_parts")
+    check(_lib.lib().svae_speed_parts(pose.data_ptr(), (C.c_int * len(flat))(*flat), (C.c_int * len(parts))(*[len(q) for q in parts]),
+                                      len(parts), W, J, out.data_ptr(), N, _stream()), "speed_parts")
     return out
 
 

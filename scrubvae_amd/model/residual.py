@@ -310,6 +310,7 @@ class ResVAE(nn.Module):
         """Start of forward / encode / decode: the master weights may have changed since the last pass, so
         the split-bf16 weight copies of every conv seen so far are refreshed in one launch (convs met for
         the first time in this pass split lazily at their first use)."""
+        self.__dict__["_main"] = None
         ops.bump_weight_epoch()
         if self._split_users:
             ops.split_weights_batched([(c, p.weight) for c, p in self._split_users.values()])
@@ -352,7 +353,7 @@ class ResVAE(nn.Module):
         Stream 0 carries the weight gradients, stream 1 the skip branches."""
         if not self.overlap_wgrad:
             return fn()
-        main = torch.cuda.current_stream()
+        main = self._main_stream()
         side = self._side_stream(k)
         ev = self._event()
         ev.record(main)
@@ -365,8 +366,16 @@ class ResVAE(nn.Module):
         """Make the main stream wait for side stream k (None: all of them)."""
         for kk in (list(self._side_dirty) if k is None else [k]):
             if kk in self._side_dirty:
-                torch.cuda.current_stream().wait_stream(self._sides[kk])
+                self._main_stream().wait_stream(self._sides[kk])
                 self._side_dirty.discard(kk)
+
+    def _main_stream(self):
+        """torch's current stream, looked up once per pass (torch.cuda.current_stream() is ~8 us a call and the reverse schedule
+        forks / joins ~60 times); _new_pass() and backward_from_seeds() drop the cached handle."""
+        m = self.__dict__.get("_main")
+        if m is None:
+            m = self.__dict__["_main"] = torch.cuda.current_stream()
+        return m
 
     def _colsum_ws(self, nbytes):
         n = nbytes // 4 + 16
@@ -404,7 +413,7 @@ class ResVAE(nn.Module):
             self._join_side()
             return self._allreduce(t, async_op=True)
         comm = self._side_stream(2)
-        comm.wait_stream(torch.cuda.current_stream())
+        comm.wait_stream(self._main_stream())
         for kk in self._side_dirty:
             comm.wait_stream(self._sides[kk])
         with torch.cuda.stream(comm):
@@ -739,6 +748,7 @@ class ResVAE(nn.Module):
             raise RuntimeError("backward called without a preceding get_batch_loss on this model")
         st = self._state
         B = st["B"]
+        self.__dict__["_main"] = None  # the autograd engine thread has its own notion of the current stream
         self._assign_grad_views()
         acc = pend.get("accumulate", False)
         enc, dec, ch = self.encoder, self.decoder, self.ch
