@@ -358,8 +358,16 @@ class ResVAE(nn.Module):
         ev = self._event()
         ev.record(main)
         side.wait_event(ev)
-        with torch.cuda.stream(side):
-            fn()
+        if ops.TIMER is None:
+            # the bodies forked here are C-ABI launches only: point them at the side stream directly
+            ops.STREAM_OVERRIDE = side.cuda_stream
+            try:
+                fn()
+            finally:
+                ops.STREAM_OVERRIDE = None
+        else:  # the launch timer records torch events on torch's current stream
+            with torch.cuda.stream(side):
+                fn()
         self._side_dirty.add(k)
 
     def _join_side(self, k=None):

@@ -31,9 +31,17 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 def _stream():
     """hipStream_t of torch's current stream.  torch.cuda.current_stream() costs ~8 us per call (about 1 ms per
     optimizer step over ~120 calls); the raw-handle query is ~20x cheaper."""
+    if STREAM_OVERRIDE is not None:
+        return STREAM_OVERRIDE
     if _raw_stream is not None:
         return _raw_stream(_device_index())
     return torch.cuda.current_stream().cuda_stream
+
+
+# hipStream_t every launch of this module goes to instead of torch's current stream (None: follow torch).  Set by
+# ResVAE._fork around a side-stream body that consists of C-ABI launches only: entering / leaving a `torch.cuda.stream`
+# context costs ~15 us of Python per fork (~0.6 ms per optimizer step over ~40 forks).
+STREAM_OVERRIDE = None
 
 
 _DEVICE_INDEX = None
@@ -237,6 +245,14 @@ class Conv:
         if kind in tuned:
             return
         tuned.add(kind)
+        global STREAM_OVERRIDE
+        if STREAM_OVERRIDE is not None:  # the timing events below live on torch's current stream: tune there
+            keep, STREAM_OVERRIDE = STREAM_OVERRIDE, None
+            try:
+                tuned.discard(kind)
+                return self._tune(kind, run)
+            finally:
+                STREAM_OVERRIDE = keep
         d = self.desc
         base = self._base_pieces(kind)
         key = f"{kind}{'@' + str(base) if base else ''}:{d.batch}:{d.l_in}:{d.c_in}:{d.c_out}:{d.ld_in}:{d.ld_out}:{d.kernel}:{d.stride}:{d.padding}:{d.transposed}"
