@@ -1213,6 +1213,22 @@ static int launch_halo(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int
   return SVAE_OK;
 }
 
+// V = 9: the halo kernel on 256-row tiles (code 9128NNN; 8 waves of 64 x 64): half the weight-piece bytes per FLOP through
+// the vector-memory path; pays once the problem has >= 2 x 256 such row tiles (batch >= 2048 for the deep layers)
+template <int BN>
+static int launch_halo256(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
+  if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_ARG; }
+  if (rows > 528 || (pieces == 3 && rows > 320 && BN > 64)) { set_error("split gather: 256-row halo image of %d rows does not fit", rows); return SVAE_ERR_ARG; }
+  if (pieces == 3) {
+    if (rows <= 320) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 3, 4, 2, 320>), grid, dim3(512), 0, st, sa);
+    else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 64, 3, 4, 2, 528>), grid, dim3(512), 0, st, sa);
+  } else {
+    if (rows <= 320) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 2, 4, 2, 320>), grid, dim3(512), 0, st, sa);
+    else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 2, 4, 2, 528>), grid, dim3(512), 0, st, sa);
+  }
+  return SVAE_OK;
+}
+
 // tile code V*1000000 + BM*1000 + BN.  V = 0: 4 waves, double-buffered LDS;  1: 4 waves, single LDS buffer;
 // 2: 8 waves (4x2), single buffer;  3: 8 waves, double-buffered (BM = 128 only);
 // 4: wave-specialised, 4 producer + 8 consumer waves, 2 tiles in flight;  5: same with 4 consumers;
@@ -1221,11 +1237,21 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
   GatherArgs& g = sa.g;
   Tile t;
   if (!decode_tile(code, t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
+  const int v = t.dma;
+  if (v == 9) {  // 256-row halo tiles, encoded with a 128 row field
+    if (t.bm != 128) { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_ARG; }
+    for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + 255) / 256);
+    const int nb = g.blocks_m[0] + g.blocks_m[1];
+    if (nb == 0) return SVAE_OK;
+    dim3 grid9(nb, (g.N + t.bn - 1) / t.bn);
+    if (int e = (t.bn == 128 ? launch_halo256<128>(sa, grid9, st, pieces, halo_rows(g, 256))
+                             : launch_halo256<64>(sa, grid9, st, pieces, halo_rows(g, 256)))) return e;
+    return check_launch("gather_halo_bf16s<256>");
+  }
   for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + t.bm - 1) / t.bm);
   const int bm = g.blocks_m[0] + g.blocks_m[1];
   if (bm == 0) return SVAE_OK;
   dim3 grid(bm, (g.N + t.bn - 1) / t.bn);
-  const int v = t.dma;
 #ifdef SVAE_ABLATION_KERNELS
 #define SVAE_ABLATION_CASE(BM_, BN_) \
   else if (v >= 10 && v < 26 && BM_ == 128 && BN_ == 128 && pieces == 3) launch_split_dbg(sa, grid, st, v - 10);
@@ -1329,6 +1355,7 @@ extern "C" int svae_conv_split_tile(const svae_conv_desc* d, int kind, int* bm, 
   if (!decode_tile(d->tile[kind], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
   *bm = t.bm; *bn = t.bn; *variant = t.dma; *rmax = 0;
   if (t.dma == 8) { const int r = halo_rows(g, 128); *rmax = r <= 160 ? 160 : 264; }
+  if (t.dma == 9) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 320 ? 320 : 528; }
   return SVAE_OK;
 }
 

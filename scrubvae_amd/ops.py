@@ -134,7 +134,8 @@ SPLIT_MIN_FLOPS = float(os.environ.get("SVAE_SPLIT_MIN_FLOPS", 2e9))
 # 6 / 7: the same with 3 tiles in flight; 8: halo-image kernel (BM = 128)
 _SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2128064, 3128128, 3128064)
                        + (4128128, 4128064, 4064128) + tuple(5000000 + c for c in _TILES)
-                       + (6128128, 6128064, 6064128) + tuple(7000000 + c for c in _TILES) + (8128128, 8128064))
+                       + (6128128, 6128064, 6064128) + tuple(7000000 + c for c in _TILES) + (8128128, 8128064)
+                       + (9128128, 9128064))  # 9: halo kernel on 256-row tiles (the row field of the code stays 128)
 _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2, 1"}
 # 1BBBNNN: single LDS buffer; 256-edge tiles: 8 waves, half the operand bytes per FLOP through the vector-memory path
 _WGRAD_BIG = (256256, 256128, 128256)
@@ -302,7 +303,7 @@ class Conv:
                 check(_lib.lib().svae_conv_split_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn), C.byref(v),
                                                       C.byref(rm)), "conv_split_tile")
                 v = v.value
-                if v == 8:
+                if v in (8, 9):
                     names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {kp}, 4, 2, {rm.value}>"
                 elif v >= 4:
                     cw = "2, 2" if v in (5, 7) else ("4, 2" if bm.value == 128 else "2, 4")

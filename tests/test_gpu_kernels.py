@@ -420,9 +420,9 @@ def _split_cases():
     for case in CONV_CASES:
         for code in (128128, 64128, 128064, 64064, 1128128, 1064128, 1128064, 1064064, 2128128, 2128064, 3128128, 3128064,
                      4128128, 4128064, 4064128, 5128128, 5128064, 5064128, 5064064,
-                     6128128, 6128064, 6064128, 7128128, 7128064, 7064128, 7064064, 8128128, 8128064, 0):
+                     6128128, 6128064, 6064128, 7128128, 7128064, 7064128, 7064064, 8128128, 8128064, 9128128, 9128064, 0):
             out.append((case, code, 3))
-        for code in (64064, 2128064, 3128128, 4128128, 5064064, 8128128, 8128064):  # 2 pieces: the backward pass of bf16x6b3
+        for code in (64064, 2128064, 3128128, 4128128, 5064064, 8128128, 8128064, 9128128, 9128064):  # 2 pieces: the backward pass of bf16x6b3
             out.append((case, code, 2))
         out.append((case, 1128064, 1))
     return out
@@ -448,7 +448,13 @@ def test_split_gather_kernels(ops, case, code, pieces):
     bd = torch.zeros(cv.c_out_p); bd[:Cout] = b.float(); bd = bd.cuda()
     yd = torch.full((B * cv.l_out, cv.c_out_p), float("nan"), device="cuda")
     tol = _SPLIT_TOL[pieces]
-    cv.fwd(to_nlc(x.detach()), wd, bd, yd)
+    try:
+        cv.fwd(to_nlc(x.detach()), wd, bd, yd)
+        cv.dgrad(to_nlc(dy), wd, torch.empty(B * L, cv.c_in_p, device="cuda"))
+    except RuntimeError as e:
+        if code // 1000000 == 9 and "does not fit" in str(e):
+            pytest.skip("256-row halo image larger than LDS for this geometry (the tuner skips it the same way)")
+        raise
     assert relerr(from_nlc(yd, B, cv.l_out, Cout), y.detach()) < tol * math.sqrt(Cin * k) + tol
     assert float(yd[:, Cout:].abs().max() if cv.c_out_p > Cout else 0) == 0.0
     cv.fwd(to_nlc(x.detach()), wd, bd, yd, accumulate=True)

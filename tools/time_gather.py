@@ -1,0 +1,34 @@
+"""Time forward / data-gradient of a few layers for given split-gather tile codes (kernel experiments)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scrubvae_amd import ops
+B = int(os.environ.get("B", 1024))
+LAYERS = [("enc3.c3", 4, 512, 1024, 5, 1, 2, False), ("dec0.sk", 8, 1024, 512, 6, 1, 2, False), ("dec0.t1", 4, 1024, 512, 5, 1, 2, True),
+          ("enc2.c3", 8, 256, 512, 5, 1, 2, False), ("dec1.sk", 14, 512, 256, 6, 1, 2, False), ("enc1.c3", 16, 128, 256, 5, 1, 2, False)]
+codes = [int(c) for c in sys.argv[1:]] or [8128128, 9128128]
+def timeit(fn):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / 20 * 1e-3
+for name, l_in, cin, cout, k, s, p, tr in LAYERS:
+    for kind, pieces in (("fwd", 3), ("dgrad", 2)):
+        row = []
+        for code in codes:
+            cv = ops.Conv(B, l_in, cin, cout, k, s, p, 1, tr, pieces=3)
+            cv.__dict__["_tuned"] = {"fwd", "dgrad", "wgrad"}
+            cv._set_choice(kind, pieces, code)
+            x = torch.randn(B * l_in, cv.c_in_p, device="cuda")
+            w = torch.randn(*cv.weight_shape, device="cuda") * 0.05
+            y = torch.empty(B * cv.l_out, cv.c_out_p, device="cuda")
+            ops.bump_weight_epoch()
+            try:
+                t = timeit((lambda: cv.fwd(x, w, None, y)) if kind == "fwd" else (lambda: cv.dgrad(y, w, x)))
+                row.append(f"{code}: {t*1e6:6.1f} us {cv.flops/t/1e12:6.1f} TF")
+            except RuntimeError as e:
+                row.append(f"{code}: n/a")
+        print(f"{name:8s} {kind:5s} " + " | ".join(row))
