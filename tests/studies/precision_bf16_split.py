@@ -16,7 +16,7 @@ from oracle import scvae_oracle as O  # noqa: E402
 from tests.test_oracle_golden import load_fixture, rel  # noqa: E402
 
 # wgrad / dgrad: optional (pieces, products) for the weight-gradient / data-gradient contractions only
-MODE = {"pieces": 2, "products": 3, "wgrad": None, "dgrad": None}
+MODE = {"pieces": 2, "products": 3, "wgrad": None, "dgrad": None, "fwd_b_pieces": None}  # fwd_b_pieces: weight pieces of the forward only
 
 
 def split(x, n):
@@ -42,8 +42,12 @@ def contract(fn, a, b, wgrad=False, dgrad=False):
         pieces, products = MODE["dgrad"]
     if pieces == 0:
         return fn(a, b)
-    A, B = split(a, pieces), split(b, pieces)
-    order = sorted(((i, j) for i in range(pieces) for j in range(pieces)), key=lambda t: (t[0] + t[1], t))[:products]
+    pb = pieces
+    if not wgrad and not dgrad and MODE.get("fwd_b_pieces"):
+        pb = MODE["fwd_b_pieces"]  # forward only: fewer weight pieces (a0..a2 x b0..b1, terms with i + j <= 2)
+    A, B = split(a, pieces), split(b, pb)
+    order = sorted(((i, j) for i in range(pieces) for j in range(pb)), key=lambda t: (t[0] + t[1], t))
+    order = [t for t in order if t[0] + t[1] <= pieces - 1] if pb != pieces else order[:products]
     acc = None
     for i, j in reversed(order):  # small terms first
         t = fn(A[i], B[j])
@@ -139,10 +143,11 @@ def run(name, golden):
     rows = []
     for label, mode in (("fp32", (0, 0)), ("bf16x1", (1, 1)), ("bf16x3", (2, 3)), ("bf16x4", (2, 4)), ("bf16x6", (3, 6)),
                         ("x6+w:x3", (3, 6, (2, 3))), ("x6+w:x1", (3, 6, (1, 1))), ("x6+b:x3", (3, 6, (2, 3), (2, 3))),
-                        ("x6+b:x4", (3, 6, (2, 3), (2, 4)))):
+                        ("x6+b:x4", (3, 6, (2, 3), (2, 4))), ("f5+b:x3", (3, 6, (2, 3), (2, 3), 2))):
         MODE["pieces"], MODE["products"] = mode[:2]
         MODE["wgrad"] = mode[2] if len(mode) > 2 else None
         MODE["dgrad"] = mode[3] if len(mode) > 3 else None
+        MODE["fwd_b_pieces"] = mode[4] if len(mode) > 4 else None
         if mode[0] == 0:
             got = base
         else:
