@@ -1,0 +1,46 @@
+"""bench.py's output contract (one JSON line on stdout with the fields the driver reads), on a small batch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def test_bench_defaults_match_baseline_config():
+    sys.path.insert(0, ROOT)
+    import bench
+    old = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = old
+    assert (a.gpus, a.batch, a.window, a.joints) == (1, 1024, 64, 23)      # BASELINE configs[1]
+    assert a.channel_list == [64, 128, 256, 512, 1024] and not a.full and not a.h2d and not a.graph
+    assert a.precision in bench.PRODUCTS
+
+
+@pytest.mark.gpu
+def test_bench_prints_exactly_one_json_line_with_the_contract_fields():
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "64"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert REQUIRED <= set(d), REQUIRED - set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "windows/s" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) <= 0.01 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["elbo_match"]["ok"] is True
