@@ -222,6 +222,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # like train_test_epoch: the steps run on the high-priority compute stream (trainer.on_compute_stream)
+    from scrubvae_amd.train.trainer import on_compute_stream
+    torch.cuda.synchronize()
+    hp = on_compute_stream("cuda")
+    hp.__enter__()
     for _ in range(args.warmup):
         step()
     if args.serial_streams:
@@ -258,6 +263,7 @@ def main():
         dt_serial = time.perf_counter() - t1
         ops.TIMER = None
         model.overlap_wgrad = keep
+    hp.__exit__(None, None, None)
     if world > 1:  # MAX over ranks
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
