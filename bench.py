@@ -4,24 +4,35 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): synthetic 64-frame, 23-joint mouse skeletons, default
-residual-CNN channels [64,128,256,512,1024], z=32, batch 1024 per GPU, recon + KL
-(loss = {jpe, root, prior}), AdamW, fp32 compute (exact-fp32 MFMA).  A step = forward + all
-configured losses + backward + grad-norm + optimizer step, inputs already resident in HBM.
-Weak scaling: the per-GPU batch is fixed as N grows; every loss is normalised by the global
-batch, gradients are summed over ranks with RCCL and BatchNorm statistics are synchronised,
-so N ranks compute the 1-rank result at the global batch.
+Headline workload = BASELINE.json configs[2] (the N=1 point of the configs[3] data-parallel series): the FULL SC-VAE --
+conditional decoder + two gradient-reversal ensembles + the adversarial net -- on synthetic 64-frame, 23-joint mouse
+skeletons, default residual-CNN channels [64,128,256,512,1024], z=32, 4096 windows per GPU, AdamW.  configs[1] (1024
+windows per GPU, recon + KL only) is measured in the same run at N=1 and reported as the `secondary` object of the same
+JSON line (`--workload config1` makes it the headline instead).
+
+A step = forward + all configured losses + backward + grad-norm / clip + optimizer step, inputs already resident in HBM.
+Arithmetic: fp32 storage and accumulation everywhere; the large contractions run on the bf16 matrix cores with every fp32
+operand split into bf16 pieces (default `--precision bf16x6b3`: 3 pieces / 6 products forward -- outputs, losses and the
+ELBO are fp32-accurate --, 2 pieces / 3 products for the data- and weight-gradient contractions).
+Weak scaling: the per-GPU batch is fixed as N grows; every loss is normalised by the global batch and gradients are summed
+over ranks with RCCL.  BatchNorm batch statistics are per rank by default (the semantics of torch DistributedDataParallel
+around the reference model); `--sync-bn` all-reduces them so that N ranks reproduce the 1-rank step at the global batch.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     -- the dominant kernel (fp32 MFMA implicit-GEMM), algorithmic FLOPs / launch
-                  over its mean launch time, measured live with HIP events in the timed region;
-  cpu_baseline -- the CPU oracle (oracle/scvae_oracle.py, stock PyTorch-CPU ops = the
-                  reference's own arithmetic) timed on this box's host cores on a bounded
-                  sample of the same workload.
+  roofline     -- the dominant GEMM kernel template: algorithmic FLOPs per launch over its mean launch time, measured live
+                  with HIP events in a second timed region (side streams serialised), against the dense bf16 MFMA peak
+                  divided by the matrix-core products per algorithmic multiply; `traffic` = HBM bytes per launch from the
+                  committed rocprofv3 PMC passes of this same command (profiles/);
+  cpu_baseline -- the CPU oracle (oracle/scvae_oracle.py, stock PyTorch-CPU ops = the reference's own arithmetic) timed on
+                  ALL host cores this process may use, on a bounded sample of the same workload at the SAME batch; its
+                  first step is also the reference of the metric's ELBO-match condition (`elbo_match`: the HIP path with
+                  the oracle's weights, batch, noise and shuffle, every loss term within 1e-4 relative);
+  secondary    -- configs[1] measured the same way (N=1 only).
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -33,6 +44,10 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 PRODUCTS = {"f32": 1, "bf16x6": 6, "bf16x6w3": 6, "bf16x6b3": 6, "bf16x3": 3, "bf16": 1}  # matrix-core products per algorithmic multiply (fwd / dgrad)
+CHANNELS = [64, 128, 256, 512, 1024]
+WIDE6 = [64, 128, 256, 512, 1024, 2048, 4096]
+ARENA = [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]
+WORKLOADS = {"config2": dict(full=True, batch=4096), "config1": dict(full=False, batch=1024)}
 
 
 def parse():
@@ -40,24 +55,25 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="windows per GPU")
+    ap.add_argument("--workload", default="config2", choices=list(WORKLOADS),
+                    help="headline workload: config2 = BASELINE configs[2], full SC-VAE heads, 4096 windows/GPU (default); "
+                         "config1 = configs[1], recon+KL, 1024 windows/GPU")
+    ap.add_argument("--batch", type=int, default=None, help="windows per GPU (default: the workload's)")
+    ap.add_argument("--full", action="store_true", help="force the full head set (conditional + grad-reversal + adversarial) on")
+    ap.add_argument("--no-heads", action="store_true", help="force recon + KL only")
     ap.add_argument("--joints", type=int, default=23)
     ap.add_argument("--window", type=int, default=64)
     ap.add_argument("--channels", default=",".join(map(str, CHANNELS)),
                     help="model.channel, comma separated; 'wide6' = configs[4]'s six blocks 64..4096 (use with --window 256)")
-    ap.add_argument("--full", action="store_true", help="configs[2]: conditional + grad-reversal + adversarial heads")
     ap.add_argument("--sync-bn", action="store_true",
-                    help="N>1: all-reduce the BatchNorm batch statistics (32 small collectives per step) so that N ranks reproduce "
-                         "the 1-rank step at the global batch exactly; default = per-rank statistics, the semantics of "
-                         "torch DistributedDataParallel around the reference model")
-    ap.add_argument("--local-bn", action="store_true", help="(default; kept for older command lines)")
+                    help="N>1: all-reduce the BatchNorm batch statistics (one fused buffer per BatchNorm and direction) so that N "
+                         "ranks reproduce the 1-rank step at the global batch exactly; default = per-rank statistics")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph (single GPU)")
     ap.add_argument("--precision", default=os.environ.get("SVAE_PRECISION", "bf16x6b3"), choices=list(PRODUCTS),
                     help="arithmetic of the large contractions: f32 = fp32 MFMA; bf16x6 = fp32-accurate 3-piece split on the bf16 "
                          "matrix cores (6 products); bf16x6w3 = the same with 2 pieces / 3 products for the weight-gradient "
-                         "contractions (gradient error vs fp64 unchanged, DESIGN.md 4); bf16x6b3 = 3 products for the whole "
-                         "backward pass, 6 for the forward; bf16x3 / bf16 = 2 / 1 pieces everywhere "
-                         "(reduced accuracy, study only)")
+                         "contractions; bf16x6b3 = 3 products for the whole backward pass, 6 for the forward; bf16x3 / bf16 = "
+                         "2 / 1 pieces everywhere (reduced accuracy, study only)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="timed region without the concurrent side streams (what the roofline region always uses)")
     ap.add_argument("--h2d", action="store_true",
@@ -65,20 +81,20 @@ def parse():
                          "never the headline value: the metric is defined with inputs resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] measurement reported as `secondary`")
     ap.add_argument("--timer-kinds", default="fwd,dgrad", help="GEMM kinds bracketed with HIP events (fwd,dgrad,wgrad)")
     args = ap.parse_args()
     args.channel_list = WIDE6 if args.channels == "wide6" else [int(c) for c in args.channels.split(",")]
+    wl = WORKLOADS[args.workload]
+    if args.batch is None:
+        args.batch = wl["batch"]
+    args.full = (wl["full"] or args.full) and not args.no_heads
     return args
 
 
-CHANNELS = [64, 128, 256, 512, 1024]
-WIDE6 = [64, 128, 256, 512, 1024, 2048, 4096]
-ARENA = [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]
-
-
-def make_cfg(args):
+def make_cfg(full):
     method, feats, loss = {}, [], {"jpe": 1.0, "root": 1.0, "prior": 1.0}
-    if args.full:
+    if full:
         method = {"conditional": ["avg_speed_3d", "heading"], "grad_reversal": ["avg_speed_3d", "heading"],
                   "adversarial_net": ["heading"]}
         feats = ["avg_speed_3d", "heading"]
@@ -86,50 +102,88 @@ def make_cfg(args):
     return method, feats, loss
 
 
-def build_model(args, method, feats, tree):
+def build_model(args, full, method, feats, tree):
     from scrubvae_amd.get import model as get_model
     mc = dict(type="rcnn", kernel=5, z_dim=32, window=args.window, activation="prelu", diag=True,
               init_dilation=None, prior="gaussian", channel=args.channel_list)
     dis = dict(method=method, alpha=1.0, features=feats)
     torch.manual_seed(0)
     m = get_model(mc, None, None, dis, args.joints, "midfwd", arena_size=torch.tensor(ARENA), kinematic_tree=tree,
-                  discrete_classes={"ids": torch.arange(4)} if args.full else None, device="cuda", verbose=0)
+                  discrete_classes={"ids": torch.arange(4)} if full else None, device="cuda", verbose=0)
     return m, dis
 
 
-def cpu_baseline(args, method, feats, loss, sample_b=128, steps=50):
-    """cpu_baseline leg: the CPU oracle's train_step (the only place bench.py touches oracle/)
-    on a bounded sample (sample_b windows) of the same workload."""
+def workload_name(args, full, B):
+    base = ("configs[2] full SC-VAE (conditional + grad_reversal x2 + adversarial_net), AdamW" if full else
+            "configs[4] wide six-block rcnn, recon+KL (jpe+root+prior), AdamW" if args.channel_list == WIDE6 else
+            "configs[1] mouse-skeleton rcnn, recon+KL (jpe+root+prior), AdamW")
+    return base + f", batch {B}/GPU, window {args.window}, {args.joints} joints, z=32, channels [{','.join(map(str, args.channel_list))}]"
+
+
+def profile_tag(args, full, B):
+    """Name of the committed PMC summaries of this workload (profiles/r*_pmc_traffic_<tag>.json), None for ad-hoc shapes."""
+    if args.channel_list != CHANNELS or args.window != 64 or args.joints != 23:
+        return None
+    if full and B == 4096:
+        return "config2_b4096"
+    if not full and B == 1024:
+        return "config1_b1024"
+    return None
+
+
+def usable_cpus():
+    """CPUs this process can actually run on at once: its affinity mask, capped by the cgroup CPU quota (the GPU boxes expose
+    all 256 host cores in the mask but give the job a 16-CPU quota: more runnable threads than that only throttle)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(args, full, B, max_seconds=24.0):
+    """cpu_baseline leg: the CPU oracle's train_step (the only place bench.py touches oracle/) at the workload's own batch,
+    on every host core this process may use.  The first (warm-up) step is the ELBO reference for `elbo_match`."""
     from oracle import scvae_oracle as O
-    # keep the sample at ~10-30 s of CPU work whatever the model size (default model: 0.76 GFLOP/window/step)
+    method, feats, loss = make_cfg(full)
+
     def cost(ch, w):
         return sum(a * b * (w >> (i + 1)) for i, (a, b) in enumerate(zip(ch, ch[1:])))
     work = cost(args.channel_list, args.window) / cost(CHANNELS, 64)
-    if work > 1.5:
-        sample_b, steps = max(4, int(128 / work) // 4 * 4), max(2, int(50 / work))
+    sample_b = B if work <= 1.5 else max(4, int(min(B, 128 / work)) // 4 * 4)  # wide / long models: a smaller sample
     cfg = O.OracleConfig(n_keypts=args.joints, window=args.window, z_dim=32, kernel=5, diag=True, channel=tuple(args.channel_list),
                          arena_size=torch.tensor(ARENA), kinematic_tree=O.skeleton_tree(args.joints), method=method,
-                         features=feats, discrete_classes={"ids": torch.arange(4)} if args.full else None)
-    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))  # the box's CPU share
+                         features=feats, discrete_classes={"ids": torch.arange(4)} if full else None)
+    threads = usable_cpus()  # every core the box gives this process
+    torch.set_num_threads(threads)
     sd = O.init_state_dict(cfg, seed=0)
     data = O.synth_batch(cfg, sample_b, seed=0)
     eps = torch.randn(sample_b, cfg.z_dim)
     perm = {k: torch.randperm(sample_b) for k in cfg.method.get("adversarial_net", [])}
     state = {}
+    t0 = time.perf_counter()
     bl0, _, _, _ = O.train_step(sd, cfg, data, loss, eps, adv_perm=perm, opt_state=state)  # warm-up; also the ELBO reference
-    elbo = elbo_check(args, cfg, sd, data, eps, perm, loss, method, feats, bl0)
+    t_first = time.perf_counter() - t0
+    elbo = elbo_check(args, full, cfg, sd, data, eps, perm, loss, method, feats, bl0)
+    steps = int(max(2, min(50, max_seconds / max(t_first, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(steps):
         _, _, sd, _ = O.train_step(sd, cfg, data, loss, eps, adv_perm=perm, opt_state=state)
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(sample_b / dt, 2), "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} optimizer steps of the CPU oracle at batch {sample_b} (same model/loss config), {dt*1e3:.0f} ms/step",
+            "host_cores": os.cpu_count(), "cpu_quota": usable_cpus(), "threads": torch.get_num_threads(),
+            "sample": f"{steps} optimizer steps of the CPU oracle at batch {sample_b} (same model / loss config as the timed GPU "
+                      f"workload), {dt*1e3:.0f} ms/step; torch intra-op threads = every CPU this job may use (affinity mask capped by "
+                      f"its cgroup CPU quota; the host has {os.cpu_count()} cores)",
             "elbo_match": elbo}
 
 
-def elbo_check(args, cfg, sd, data, eps, perm, loss, method, feats, oracle_losses):
-    """The "ELBO-match" condition of the metric, checked on the benchmark's own model size and precision: the oracle's
-    weights, batch and noise on the HIP path; relative deviation of every loss term (bound: 1e-4)."""
+def elbo_check(args, full, cfg, sd, data, eps, perm, loss, method, feats, oracle_losses):
+    """The "ELBO-match" condition of the metric on the benchmark's own model, batch, precision and tile table: the oracle's
+    weights, batch, noise and shuffle on the HIP path; relative deviation of every loss term (bound: 1e-4)."""
     from scrubvae_amd.get import model as get_model
     from scrubvae_amd.train.losses import get_batch_loss
     mc = dict(type="rcnn", kernel=5, z_dim=32, window=args.window, activation="prelu", diag=True, init_dilation=None,
@@ -150,12 +204,14 @@ def elbo_check(args, cfg, sd, data, eps, perm, loss, method, feats, oracle_losse
             "total_rel_dev": float(f"{rel['total']:.3g}"), "bound": 1e-4, "ok": bool(worst <= 1e-4)}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 corrections applied by
-    tools/summarize_pmc.py); None when no summary for this kernel is committed."""
+def pmc_traffic(kernel, tag):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this workload (separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this same command, gfx950 corrections applied by tools/summarize_pmc.py); None when no summary
+    for this workload / kernel is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if tag is None:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_pmc_traffic.json")))
     if not files:
         return None
     try:
@@ -166,27 +222,16 @@ def pmc_traffic(kernel):
         return None
 
 
-def main():
-    args = parse()
-    # stdout carries exactly ONE line (the JSON): whatever libraries print while the job runs (RCCL's version banner,
-    # gloo's connection messages, ...) is sent to stderr instead -- file descriptor 1 is pointed at stderr until the end
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+def run_workload(args, full, B, rank, world, roofline=True):
+    """Times `args.steps` optimizer steps of one workload (after `args.warmup` untimed ones); returns the result fields."""
     from scrubvae_amd import parallel, ops
-    from scrubvae_amd.train.losses import get_batch_loss
-    from scrubvae_amd.train.trainer import FusedAdam, clip_grad_norm_
-    rank, local, world = parallel.init_distributed()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-    ops.set_precision(args.precision)
     from scrubvae_amd.data import synthetic
-    method, feats, loss = make_cfg(args)
-    B = args.batch
+    from scrubvae_amd.train.losses import get_batch_loss
+    from scrubvae_amd.train.trainer import FusedAdam, clip_grad_norm_, on_compute_stream
+    method, feats, loss = make_cfg(full)
     data, tree = synthetic.make_batch(args.joints, args.window, B, seed=100 + rank, device="cuda")
     data0 = data
-    model, dis = build_model(args, method, feats, tree)
+    model, dis = build_model(args, full, method, feats, tree)
     parallel.attach(model, sync_bn=args.sync_bn)
     model.defer_tail = True  # one fused tail launch per step (outputs + losses + seed gradients)
     opt = FusedAdam(model, lr=1e-4, weight_decay=0.01, decoupled=True)
@@ -196,7 +241,7 @@ def main():
     if args.graph:
         from scrubvae_amd.train.trainer import GraphedStep
         graphed = GraphedStep(model, opt, loss, dis, data)
-        args.no_roofline = True  # per-launch events cannot be recorded inside a replay
+        roofline = False  # per-launch events cannot be recorded inside a replay
 
     feed = None
     if args.h2d:  # every step consumes a batch that DevicePrefetcher copied from pinned host memory one step ahead
@@ -223,7 +268,6 @@ def main():
         torch.cuda.synchronize()
 
     # like train_test_epoch: the steps run on the high-priority compute stream (trainer.on_compute_stream)
-    from scrubvae_amd.train.trainer import on_compute_stream
     torch.cuda.synchronize()
     hp = on_compute_stream("cuda")
     hp.__enter__()
@@ -231,8 +275,7 @@ def main():
         step()
     if args.serial_streams:
         model.overlap_wgrad = False
-    # ---- headline timed region: exactly K steps, barrier + synchronize on both sides, no
-    # per-launch instrumentation
+    # ---- headline timed region: exactly K steps, barrier + synchronize on both sides, no per-launch instrumentation
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -240,12 +283,12 @@ def main():
     t_host = time.perf_counter() - t0  # all launches of the K steps are queued (the GPU is still working)
     barrier()
     dt = time.perf_counter() - t0
-    # ---- roofline region: the same K steps again with the side streams serialised and HIP
-    # events around every launch of the dominant GEMM template.  In the headline region three
-    # HIP streams run kernels concurrently on shared CUs, so a launch's start-to-end time is
-    # not the kernel's own time there; serialised, it is.
+    # ---- roofline region: the same K steps again with the side streams serialised and HIP events around every launch of
+    # the dominant GEMM template.  In the headline region three HIP streams run kernels concurrently on shared CUs, so a
+    # launch's start-to-end time is not the kernel's own time there; serialised, it is.
     timer = probe = None
-    if not args.no_roofline and graphed is None:
+    dt_serial = None
+    if roofline and graphed is None:
         keep = model.overlap_wgrad
         model.overlap_wgrad = False
         probe = ops.LaunchTimer(kinds=tuple(args.timer_kinds.split(",")))
@@ -268,73 +311,99 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
-    total_loss = float(bl["total"].detach())
+    res = {"value": round(B * world * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3), "final_total_loss": float(bl["total"].detach()),
+           "workload": workload_name(args, full, B), "batch_per_gpu": B}
+    if timer is not None:
+        summ = timer.summary()
+        if summ:
+            kname, s = max(summ.items(), key=lambda kv: kv[1]["ms"])  # the GEMM template instance with the largest total time
+            tf = s["flops"] / (s["ms"] * 1e-3) / 1e12
+            split_kernel = "bf16s" in kname
+            pm = re.search(r"bf16s\w*<\d+, \d+, (\d)", kname)  # products per multiply of THIS template: its piece count
+            k_products = {3: 6, 2: 3, 1: 1}[int(pm.group(1))] if pm else PRODUCTS[args.precision]
+            peak = PEAK_BF16_MFMA_TFLOPS / k_products if split_kernel else PEAK_F32_MFMA_TFLOPS
+            res["roofline"] = {
+                "measured": f"second timed region of {args.steps} steps with the side HIP streams serialised "
+                            f"({dt_serial / args.steps * 1e3:.3f} ms/step; the headline region overlaps kernels on 3 streams, "
+                            "where a launch's duration is not the kernel's own time); profiles/ holds the rocprofv3 summary of "
+                            "`bench.py --serial-streams` for the same workload",
+                "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                "traffic": pmc_traffic("svae::" + kname, profile_tag(args, full, B)),
+                "peak_note": (f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {k_products} matrix-core products per "
+                              "algorithmic multiply (achieved counts algorithmic FLOPs)"
+                              if split_kernel else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                "kernel": "svae::" + kname, "launches_per_step": s["launches"] // args.steps,
+                "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2),
+                "avg_launch_gflop": round(s["flops"] / s["launches"] / 1e9, 3),
+                "probe_step_all_gemm_templates": {
+                    k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                        "avg_us": round(v["ms"] * 1e3 / v["launches"], 2), "launches_per_step": v["launches"]}
+                    for k, v in sorted(probe.summary().items())}}
+    del model, opt, graphed
+    torch.cuda.empty_cache()
+    return res
+
+
+def precision_text(p):
+    if p == "f32":
+        return "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+    tail = {"bf16x6": " (fp32-accurate, DESIGN.md 4)",
+            "bf16x6w3": " forward and data-gradient (fp32-accurate), 3 (2 pieces) for the weight-gradient contractions "
+                        "(gradient error vs fp64 unchanged, DESIGN.md 4)",
+            "bf16x6b3": " forward (outputs, losses, ELBO: fp32-accurate), 3 (2 pieces) for the data- and weight-gradient "
+                        "contractions (whole-step gradients checked against the CPU oracle at the benchmark's size, "
+                        "tests/test_gpu_fullsize.py)"}.get(p, " (reduced accuracy)")
+    return (f"{p}: fp32 storage and accumulation; every large contraction splits its fp32 operands into bf16 pieces and runs "
+            f"{PRODUCTS[p]} cross product(s) on v_mfma_f32_32x32x16_bf16" + tail)
+
+
+def main():
+    args = parse()
+    # stdout carries exactly ONE line (the JSON): whatever libraries print while the job runs (RCCL's version banner,
+    # gloo's connection messages, ...) is sent to stderr instead -- file descriptor 1 is pointed at stderr until the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    from scrubvae_amd import parallel, ops
+    rank, local, world = parallel.init_distributed()  # reads the torchrun environment; no GPU call before this point
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    ops.set_precision(args.precision)
+    B = args.batch
+    head = run_workload(args, args.full, B, rank, world, roofline=not args.no_roofline)
 
     if rank == 0:
-        ms = dt / args.steps * 1e3
         out = {
             "metric": f"pose-windows/sec (ELBO-match) on synthetic {args.window}-frame mouse skeletons",
-            "value": round(B * world * args.steps / dt, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "value": head["value"], "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else f"f32 ({args.precision} split on the bf16 matrix cores)",
             "data": "synthetic",
-            "config": {"workload": ("configs[2] full SC-VAE (conditional + grad_reversal x2 + adversarial_net)" if args.full else
-                                    "configs[4] wide six-block rcnn, recon+KL (jpe+root+prior), AdamW" if args.channel_list == WIDE6 else
-                                    "configs[1] mouse-skeleton rcnn, recon+KL (jpe+root+prior), AdamW") +
-                                   f", batch {B}/GPU, window {args.window}, {args.joints} joints, z=32, channels [{','.join(map(str, args.channel_list))}]",
-                       "batch_per_gpu": B, "global_batch": B * world, "window": args.window, "joints": args.joints,
-                       "launch": "hipGraph replay" if args.graph else "eager launches",
+            "config": {"workload": head["workload"], "batch_per_gpu": B, "global_batch": B * world, "window": args.window,
+                       "joints": args.joints, "launch": "hipGraph replay" if args.graph else "eager launches",
                        "inputs": ("copied from pinned host memory for every step, one batch ahead on a copy stream (PCIe-inclusive)"
                                   if args.h2d else "resident in HBM"),
                        "streams": "serialised" if args.serial_streams else "3 HIP streams (weight gradients / skip branches overlap the main chain)",
-                       "precision": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.precision == "f32" else
-                                     f"{args.precision}: fp32 storage and accumulation; every large contraction splits its fp32 operands into "
-                                     f"bf16 pieces and runs {PRODUCTS[args.precision]} cross product(s) on v_mfma_f32_32x32x16_bf16"
-                                     + (" (fp32-accurate, DESIGN.md 4)" if args.precision == "bf16x6" else
-                                        " forward and data-gradient (fp32-accurate), 3 (2 pieces) for the weight-gradient contractions "
-                                        "(gradient error vs fp64 unchanged, DESIGN.md 4)" if args.precision == "bf16x6w3" else
-                                        " forward (outputs, losses, ELBO: fp32-accurate), 3 (2 pieces) for the data- and weight-gradient "
-                                        "contractions (gradient error vs fp64 within the fp32 path's own, DESIGN.md 4)"
-                                        if args.precision == "bf16x6b3" else " (reduced accuracy)")),
-                       "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
+                       "precision": precision_text(args.precision),
+                       "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("+syncbn" if args.sync_bn else "+localbn")),
-                       "final_total_loss": total_loss},
+                       "final_total_loss": head["final_total_loss"]},
         }
-        if timer is not None:
-            summ = timer.summary()
-            if summ:
-                # dominant kernel = the GEMM template instance with the largest total time
-                kname, s = max(summ.items(), key=lambda kv: kv[1]["ms"])
-                tf = s["flops"] / (s["ms"] * 1e-3) / 1e12
-                split_kernel = "bf16s" in kname
-                # products per algorithmic multiply of THIS template: its piece count is the third template argument
-                import re
-                pm = re.search(r"bf16s\w*<\d+, \d+, (\d)", kname)
-                k_products = {3: 6, 2: 3, 1: 1}[int(pm.group(1))] if pm else PRODUCTS[args.precision]
-                peak = PEAK_BF16_MFMA_TFLOPS / k_products if split_kernel else PEAK_F32_MFMA_TFLOPS
-                out["roofline"] = {"measured": f"second timed region of {args.steps} steps with the side HIP streams serialised "
-                                               f"({dt_serial / args.steps * 1e3:.3f} ms/step; the headline region overlaps kernels "
-                                               "on 3 streams, where a launch's duration is not the kernel's own time); "
-                                               "profiles/*serial* is the rocprofv3 summary of `bench.py --serial-streams`",
-                                   "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                                   "frac": round(tf / peak, 4),
-                                   # the committed PMC passes are of the default command (configs[1], batch 1024)
-                                   "traffic": pmc_traffic("svae::" + kname) if (args.channel_list == CHANNELS and args.window == 64 and B == 1024
-                                                                                and not args.full) else None,
-                                   "peak_note": (f"dense bf16 MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {k_products} "
-                                                 "matrix-core products per algorithmic multiply (achieved counts algorithmic FLOPs)"
-                                                 if split_kernel else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
-                                   "kernel": "svae::" + kname,
-                                   "launches_per_step": s["launches"] // args.steps,
-                                   "avg_launch_us": round(s["ms"] * 1e3 / s["launches"], 2),
-                                   "avg_launch_gflop": round(s["flops"] / s["launches"] / 1e9, 3),
-                                   "probe_step_all_gemm_templates": {
-                                       k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                           "avg_us": round(v["ms"] * 1e3 / v["launches"], 2), "launches_per_step": v["launches"]}
-                                       for k, v in sorted(probe.summary().items())}}
+        if "roofline" in head:
+            out["roofline"] = head["roofline"]
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, method, feats, loss)
+            out["cpu_baseline"] = cpu_baseline(args, args.full, B)
+        if world == 1 and not args.no_secondary and args.workload == "config2" and args.batch == WORKLOADS["config2"]["batch"] \
+                and args.channel_list == CHANNELS and args.window == 64 and not (args.graph or args.h2d or args.serial_streams):
+            w1 = WORKLOADS["config1"]
+            sec = run_workload(args, w1["full"], w1["batch"], rank, world, roofline=not args.no_roofline)
+            sec = {"metric": out["metric"], "unit": "windows/s", **sec}
+            if not args.no_cpu_baseline:
+                sec["cpu_baseline"] = cpu_baseline(args, w1["full"], w1["batch"], max_seconds=8.0)
+            out["secondary"] = sec
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:

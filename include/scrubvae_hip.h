@@ -109,6 +109,14 @@ typedef struct {
 int svae_conv_split_weights_batched(const svae_split_task* tasks, int n, void* stream);
 int svae_conv_fwd_split(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias,
                         float* y, int accumulate, int pieces, void* stream);
+/* The same launch with the train-mode BatchNorm statistics of the conv output fused into its epilogue (nn.BatchNorm1d right
+ * behind the conv, residual.py:88,112,146,173): bn_part[tile][2][c_out] = per-column (sum y, sum y^2) over the valid rows of
+ * row tile `tile`, y = the value written (bias and, with accumulate, the previous content included) -- the layout of
+ * svae_bn_stats_partial with svae_conv_fwd_stats_tiles(d) in place of svae_bn_chunks(rows); feed it to
+ * svae_bn_stats_finalize / svae_bn_reduce_partials.  Removes one full read of the conv output per BatchNorm. */
+int svae_conv_fwd_stats_tiles(const svae_conv_desc* d);
+int svae_conv_fwd_split_stats(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias,
+                              float* y, int accumulate, int pieces, float* bn_part, void* stream);
 int svae_conv_dgrad_split(const svae_conv_desc* d, const float* dy, const void* wsplit, float* dx,
                           int accumulate, int pieces, void* stream);
 int svae_conv_wgrad_split(const svae_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -287,6 +295,54 @@ int svae_inv_kin(const float* pose, const float* unit_offset_host, const svae_tr
 int svae_speed_parts(const float* pose, const int* parts_host, const int* part_len_host, int n_parts, int W, int J,
                      float* out, long long windows, void* stream);
 
+/* ------------------------------------------------------------- MLP-ensemble scrubber heads --- */
+/* G2/G3/A1: MLPEnsemble (disentangle.py:583-632) = up to four small MLPs (Linear/ReLU chains of <= 3 Linears) on the same input,
+ * as ONE launch forward and one (+ a reduction launch) backward; GRScrubber (:635-660) feeds it mu, AdvNetScrubber (:663-684)
+ * cat([mu;mu],[v;v_shuffle]).  The input is assembled in the kernel: columns [0,n0) = src0[b][0..n0), columns [n0,n0+n1) =
+ * src1[b][0..n1); halves = 2 appends a second copy of the batch (rows batch..2*batch-1) whose column `shuf_col` of src1 is read
+ * from row perm[b] (AdvNetScrubber.shuffle, :678-684; perm = int64 device array) or, when shuf_vals != NULL, is shuf_vals[b].  Weights are TIO Linear weights
+ * [K][N] (K, N = features padded to multiples of 16, pads zero) -- the model's own parameter storage, nothing repacked. */
+#define SVAE_ENS_MEMBERS 4
+#define SVAE_ENS_MAX_LAYERS 3
+typedef struct {
+  const float* w;   /* [K][N] */
+  const float* b;   /* [N] */
+  float* dw;        /* gradient destinations; NULL (both) = frozen parameters: no weight gradients for this member */
+  float* db;
+  int K, N;
+} svae_ens_layer;
+typedef struct {
+  svae_ens_layer layer[SVAE_ENS_MAX_LAYERS];
+  int n_layers;
+  float* out;          /* fwd: [rows][N_last] pre-activation outputs of the last Linear (rows = batch * halves) */
+  const float* d_out;  /* bwd: gradient with respect to `out`, same shape */
+} svae_ens_member;
+typedef struct {
+  svae_ens_member member[SVAE_ENS_MEMBERS];
+  int n_members;
+  const float* src0; int ld0, n0;
+  const float* src1; int ld1, n1;
+  const long long* perm; int shuf_col;
+  int batch, halves;
+  const float* shuf_vals;  /* optional [batch]: the shuffled column's values for the second copy, used instead of src1[perm[b]]
+                            * (data parallel: the permutation runs over the GLOBAL batch, the values come from other ranks) */
+} svae_ens_desc;
+int svae_ens_fwd(const svae_ens_desc* d, void* stream);
+/* Backward: recomputes the hidden activations, then writes parameter gradients (dw/db of every non-frozen member; summed over
+ * row tiles in a fixed order, no atomics) and the input gradient: d_src0[b][k] += coef * sum over members and halves of
+ * d/d input[b][k] for k < n0 (d_src0 may be NULL), and, when gx_raw != NULL, gx_raw[row][k] = sum over members for all rows and
+ * all K_0 input columns.  coef = -alpha is the gradient reversal (disentangle.py:541-556). */
+size_t svae_ens_bwd_workspace(const svae_ens_desc* d);
+int svae_ens_bwd(const svae_ens_desc* d, float* d_src0, int ld_d, float coef, float* gx_raw, void* ws, size_t ws_bytes,
+                 int accumulate_param_grads, void* stream);
+/* Losses of all members in one launch (losses.py:267-309).  kind 0: sum((out - target)^2) over [rows][C]; 1: CrossEntropy(sum) vs
+ * int32 labels; 2: the adversarial net's CrossEntropy applied to softmax(out) with class = (row >= rows/2) (double-softmax quirk,
+ * disentangle.py:675 + losses.py:304-307; C = 2).  outs / dpred / loss_w / grad_s are HOST arrays of n_members entries:
+ * part[m * nb + j] = loss_w[m] * (sum over the rows of block j), nb = svae_rowloss_blocks(rows); dpred[m] (may be NULL) =
+ * grad_s[m] * d loss_m / d out_m. */
+int svae_ens_loss(int kind, const float* const* outs, float* const* dpred, const float* loss_w, const float* grad_s, int n_members,
+                  const float* target, int ld_t, const int* labels, int rows, int C, int ld, float* part, void* stream);
+
 /* ------------------------------------------------------------------------- optimizer --- */
 /* O1: torch.optim.AdamW / Adam step over one flat fp32 buffer (trainer.py:60-65,165).
  * step_t = 1-based step count; decoupled != 0 => AdamW. grad_scale multiplies g first
@@ -294,11 +350,16 @@ int svae_speed_parts(const float* pose, const int* parts_host, const int* part_l
 int svae_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step_t, int decoupled,
                    float grad_scale, void* stream);
-/* hipGraph-capturable form: hyper (device, 3 floats) = {lr, lr/(1-beta1^t), 1/sqrt(1-beta2^t)},
- * refreshed by the host before every replay */
+/* hipGraph-capturable form: hyper (device, 4 floats) = {lr, lr/(1-beta1^t), 1/sqrt(1-beta2^t), t}.  The caller writes
+ * lr (stream-ordered) when the schedule changes it; svae_adam_advance, captured in front of the step, does t += 1 and
+ * derives the two bias-correction terms ON THE DEVICE, so queued replays never race a host buffer. */
 int svae_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const float* hyper,
                        float beta1, float beta2, float eps, float weight_decay, int decoupled,
                        float grad_scale, void* stream);
+int svae_adam_advance(float* hyper, float beta1, float beta2, void* stream);
+/* torch.nn.utils.clip_grad_norm_ (trainer.py:164): g *= min(1, max_norm / (sqrt(*sumsq) + 1e-6)); sumsq = device scalar
+ * holding the sum of squares of ALL gradients.  Returns without touching g when the clip does not bite. */
+int svae_clip_grads(float* g, long long n, const float* sumsq, float max_norm, void* stream);
 /* sum of squares partials for clip_grad_norm_ (trainer.py:164): part[svae_sumsq_blocks(n)] */
 int svae_sumsq_blocks(long long n);
 int svae_sumsq_partial(const float* x, long long n, float* part, void* stream);

@@ -34,6 +34,25 @@ class SplitTask(C.Structure):
 MAX_SPLIT_TASKS = 48
 
 
+ENS_MEMBERS, ENS_MAX_LAYERS = 4, 3
+
+
+class EnsLayer(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("K", C.c_int), ("N", C.c_int)]
+
+
+class EnsMember(C.Structure):
+    _fields_ = [("layer", EnsLayer * ENS_MAX_LAYERS), ("n_layers", C.c_int), ("out", C.c_void_p), ("d_out", C.c_void_p)]
+
+
+class EnsDesc(C.Structure):
+    _fields_ = [("member", EnsMember * ENS_MEMBERS), ("n_members", C.c_int),
+                ("src0", C.c_void_p), ("ld0", C.c_int), ("n0", C.c_int),
+                ("src1", C.c_void_p), ("ld1", C.c_int), ("n1", C.c_int),
+                ("perm", C.c_void_p), ("shuf_col", C.c_int), ("batch", C.c_int), ("halves", C.c_int),
+                ("shuf_vals", C.c_void_p)]
+
+
 class Tree(C.Structure):
     _fields_ = [("n_joints", C.c_int), ("n_chains", C.c_int),
                 ("chain_len", C.c_int * MAX_CHAINS),
@@ -74,6 +93,8 @@ SIGNATURES = {
     "svae_conv_split_weights": (I, [DP, P, P, P]),
     "svae_conv_split_weights_batched": (I, [C.POINTER(SplitTask), I, P]),
     "svae_conv_fwd_split": (I, [DP, P, P, P, P, I, I, P]),
+    "svae_conv_fwd_stats_tiles": (I, [DP]),
+    "svae_conv_fwd_split_stats": (I, [DP, P, P, P, P, I, I, P, P]),
     "svae_conv_dgrad_split": (I, [DP, P, P, P, I, I, P]),
     "svae_conv_wgrad_split": (I, [DP, P, P, P, P, P, SZ, I, I, P]),
     "svae_conv_split_tile": (I, [DP, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I)]),
@@ -108,6 +129,8 @@ SIGNATURES = {
     "svae_rot_blocks": (I, [LL]),
     "svae_adam_step": (I, [P, P, P, P, LL, F, F, F, F, F, I, I, F, P]),
     "svae_adam_step_dev": (I, [P, P, P, P, LL, P, F, F, F, F, I, F, P]),
+    "svae_adam_advance": (I, [P, F, F, P]),
+    "svae_clip_grads": (I, [P, LL, P, F, P]),
     "svae_sumsq_blocks": (I, [LL]),
     "svae_sumsq_partial": (I, [P, LL, P, P]),
     "svae_reduce_rows": (I, [P, I, I, F, P, I, P]),
@@ -119,6 +142,10 @@ SIGNATURES = {
     "svae_rowloss_blocks": (I, [I]),
     "svae_ce_sum": (I, [P, I, P, I, I, F, P, P, P]),
     "svae_double_softmax_ce_sum": (I, [P, I, I, F, P, P, P]),
+    "svae_ens_fwd": (I, [C.POINTER(EnsDesc), P]),
+    "svae_ens_bwd_workspace": (SZ, [C.POINTER(EnsDesc)]),
+    "svae_ens_bwd": (I, [C.POINTER(EnsDesc), P, I, F, P, P, SZ, I, P]),
+    "svae_ens_loss": (I, [I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(F), C.POINTER(F), I, P, I, P, I, I, I, P, P]),
 }
 
 _lib = None
@@ -150,6 +177,17 @@ def last_error():
     return buf.value.decode()
 
 
+ERR_SHAPE, ERR_ALIGN, ERR_WORKSPACE, ERR_LAUNCH, ERR_ARG = -1, -2, -3, -4, -5  # include/scrubvae_hip.h svae_status
+
+
+class SvaeError(RuntimeError):
+    """A non-zero svae_status; `.status` holds the code (ERR_* above)."""
+
+    def __init__(self, status, what, msg):
+        super().__init__(f"libscrubvae_hip {what} failed (status {status}): {msg}")
+        self.status = status
+
+
 def check(status, what=""):
     if status != 0:
-        raise RuntimeError(f"libscrubvae_hip {what} failed (status {status}): {last_error()}")
+        raise SvaeError(status, what, last_error())

@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["capi.hip", "gemm_f32.hip", "gemm_bf16s.hip", "elementwise.hip", "pose_tail.hip", "latent.hip", "preprocess.hip"]
+SOURCES = ["capi.hip", "gemm_f32.hip", "gemm_bf16s.hip", "elementwise.hip", "pose_tail.hip", "latent.hip", "preprocess.hip", "ensemble.hip"]
 OUT = os.path.join(CSRC, "libscrubvae_hip.so")
 
 
@@ -18,20 +18,44 @@ def needs_build():
 
 
 def build(force=False, verbose=False, ablation=False):
-    """ablation=True additionally compiles the timing-experiment kernel variants used by tools/bench_split_dbg.py
-    (parts of the work removed, wrong results) -- never part of the shipped library."""
+    """Each translation unit is compiled to its own object (in parallel, only when it or a header changed) and the objects
+    are linked into the shared library.  ablation=True additionally compiles the timing-experiment kernel variants used by
+    tools/bench_split_dbg.py (parts of the work removed, wrong results) -- never part of the shipped library."""
     if not force and not needs_build():
         return OUT
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result"]
-    if ablation:
-        cmd.append("-DSVAE_ABLATION_KERNELS")
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, "svae_internal.h"), os.path.join(CSRC, "gemm_common.h"),
+               os.path.join(CSRC, "..", "..", "include", "scrubvae_hip.h")]
+    hdr_t = max(os.path.getmtime(h) for h in headers)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + (["-DSVAE_ABLATION_KERNELS"] if ablation else [])
+    tag = "_abl" if ablation else ""
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + tag + ".o")
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_t):
+            return obj, None
+        cmd = ["hipcc"] + flags + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return obj, (r.stdout + r.stderr if r.returncode != 0 else None)
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    errs = [e for _, e in results if e]
+    if errs:
+        sys.stderr.write("\n".join(errs))
+        raise RuntimeError("hipcc failed building libscrubvae_hip.so")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in results] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libscrubvae_hip.so")
+        raise RuntimeError("hipcc failed linking libscrubvae_hip.so")
     return OUT
 
 

@@ -546,6 +546,29 @@ __global__ __launch_bounds__(256) void adam_kernel_dev(float* __restrict__ p, co
   }
 }
 
+// Device-side step counter for captured (hipGraph) optimizer steps: hyper = {lr, lr / bias_correction1, 1 / sqrt(bias_correction2),
+// step}.  Advancing it inside the graph means no host buffer is re-written while earlier replays are still queued.
+__global__ void adam_advance_kernel(float* __restrict__ hyper, float b1, float b2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double t = (double)hyper[3] + 1.0;
+  hyper[3] = (float)t;
+  hyper[1] = (float)((double)hyper[0] / (1.0 - pow((double)b1, t)));
+  hyper[2] = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+}
+
+// torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (norm + 1e-6)), norm = sqrt(*sumsq).  Every thread reads the scalar; when
+// the clip does not bite (the reference's max_norm = 1e6) the kernel returns without touching the gradients.
+__global__ __launch_bounds__(256) void clip_grads_kernel(float* __restrict__ g, long long n, const float* __restrict__ sumsq,
+                                                          float max_norm) {
+  const float coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+  if (!(coef < 1.f)) return;
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 v = ld4(g + i * 4);
+    st4(g + i * 4, make_float4(v.x * coef, v.y * coef, v.z * coef, v.w * coef));
+  }
+}
+
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
   __shared__ float red4[4];
   float s = 0.f;
@@ -795,6 +818,18 @@ extern "C" int svae_adam_step_dev(float* p, const float* g, float* m, float* v, 
   hipLaunchKernelGGL(adam_kernel_dev, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, n, hyper, beta1, beta2,
                      eps, weight_decay, decoupled, grad_scale);
   return check_launch("adam_step_dev");
+}
+
+extern "C" int svae_adam_advance(float* hyper, float beta1, float beta2, void* stream) {
+  SVAE_REQUIRE(hyper, SVAE_ERR_ARG, "adam_advance: null pointer");
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, ST(stream), hyper, beta1, beta2);
+  return check_launch("adam_advance");
+}
+
+extern "C" int svae_clip_grads(float* g, long long n, const float* sumsq, float max_norm, void* stream) {
+  SVAE_REQUIRE(g && sumsq && n > 0 && n % 4 == 0 && max_norm > 0.f, SVAE_ERR_ARG, "clip_grads: bad args");
+  hipLaunchKernelGGL(clip_grads_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, ST(stream), g, n, sumsq, max_norm);
+  return check_launch("clip_grads");
 }
 
 extern "C" int svae_sumsq_blocks(long long n) { return grid_for(n / 4, 256, 1024); }

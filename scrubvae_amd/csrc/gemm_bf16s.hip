@@ -92,6 +92,64 @@ struct SplitGatherArgs {
   int KB;                     // 32-deep k blocks per tap
 };
 
+// ---- epilogue shared by the gather kernels: C (+)= acc + bias, and -- when g.stats != NULL -- the BatchNorm batch statistics of
+// the values just written (reference: nn.BatchNorm1d in train mode right behind the conv, residual.py:88,112,146,173): per-column
+// (sum v, sum v^2) over the tile's valid rows go to stats[blockIdx.x][2][N], the layout bn_stats_partial writes per 128-row chunk,
+// so the finalize kernel sums row tiles instead of chunks and the separate statistics pass over the conv output disappears.
+// Fixed summation order (lane rows, the two half-waves, then the WR row-waves): bit-reproducible.
+template <int MT, int NT, int WM, int WN, int WR, int BN>
+__device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)[MT][NT], const long long* rowoff, int n0, int wr, int wc,
+                                              int lr, int h, float* red, int tid, int nth) {
+  float cs[NT], cq[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + wc * WN + nt * 32 + lr;
+    cs[nt] = 0.f;
+    cq[nt] = 0.f;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long off = rowoff[row];
+        if (off >= 0) {
+          float* dst = g.C + off + col;
+          float v = acc[mt][nt][r] + bv;
+          if (g.accumulate) v += *dst;
+          *dst = v;
+          cs[nt] += v;
+          cq[nt] += v * v;
+        }
+      }
+    }
+  }
+  if (g.stats == nullptr) return;  // uniform
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    cs[nt] += __shfl_xor(cs[nt], 32, 64);
+    cq[nt] += __shfl_xor(cq[nt], 32, 64);
+  }
+  __syncthreads();  // every wave is past its last LDS operand read: the staging buffers are free
+  if (h == 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c = wc * WN + nt * 32 + lr;
+      red[(0 * WR + wr) * BN + c] = cs[nt];
+      red[(1 * WR + wr) * BN + c] = cq[nt];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * BN; i += nth) {
+    const int k = i / BN, c = i - k * BN;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WR; ++w) t += red[(k * WR + w) * BN + c];
+    if (n0 + c < g.N) g.stats[((long long)blockIdx.x * 2 + k) * g.N + n0 + c] = t;
+  }
+}
+
 // ------------------------------------------------------------------ gather GEMM (fwd / dgrad)
 // BM x BN tile per workgroup of WR x WC waves.  NSTAGE = 2: double-buffered LDS, one barrier per
 // K stage (register prefetch two stages ahead);  NSTAGE = 1: one LDS buffer, two barriers per
@@ -291,26 +349,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void gather_gemm_bf16s_kernel(c
     }
   }
 
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = n0 + wc * WN + nt * 32 + lr;
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const long long off = rowoff[row];
-        if (off >= 0) {
-          float* dst = g.C + off + col;
-          float v = acc[mt][nt][r] + bv;
-          if (g.accumulate) v += *dst;
-          *dst = v;
-        }
-      }
-    }
-  }
+  tile_epilogue<MT, NT, WM, WN, WR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), tid, NTH);
 }
 
 // ------------------------------------------------- gather GEMM, wave-specialised (fwd / dgrad)
@@ -552,26 +591,7 @@ __global__ __launch_bounds__(64 * (4 + CWR * CWC)) void gather_gemm_bf16s_ws_ker
     __syncthreads();
   }
 
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = n0 + wc * WN + nt * 32 + lr;
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const long long off = rowoff[row];
-        if (off >= 0) {
-          float* dst = g.C + off + col;
-          float v = acc[mt][nt][r] + bv;
-          if (g.accumulate) v += *dst;
-          *dst = v;
-        }
-      }
-    }
-  }
+  tile_epilogue<MT, NT, WM, WN, CWR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), ctid, 64 * CWR * CWC);
 }
 
 // ----------------------------------------------------- gather GEMM with a halo image (fwd / dgrad)
@@ -809,26 +829,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
   }
   if (ns == 0) __syncthreads();  // rowoff
 
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = n0 + wc * WN + nt * 32 + lr;
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const long long off = rowoff[row];
-        if (off >= 0) {
-          float* dst = g.C + off + col;
-          float v = acc[mt][nt][r] + bv;
-          if (g.accumulate) v += *dst;
-          *dst = v;
-        }
-      }
-    }
-  }
+  tile_epilogue<MT, NT, WM, WN, WR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), tid, NTH);
 }
 
 // ---------------------------------------------------------------------------- weight split
@@ -1300,8 +1301,26 @@ extern "C" int svae_conv_split_weights(const svae_conv_desc* d, const float* w, 
   return check_launch("split_weights");
 }
 
+// row tiles of the split forward launch for the descriptor's current tile choice
+extern "C" int svae_conv_fwd_stats_tiles(const svae_conv_desc* d) {
+  if (validate(d)) return 0;
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  g.N = d->c_out;
+  build_plan(g, d, !d->transposed, d->l_out, d->l_in);
+  Tile t;
+  if (!decode_tile(d->tile[0], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
+  const int bm = t.dma == 9 ? 256 : t.bm;
+  return (int)((g.M[0] + bm - 1) / bm + (g.M[1] + bm - 1) / bm);
+}
+
 extern "C" int svae_conv_fwd_split(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias, float* y,
                                    int accumulate, int pieces, void* stream) {
+  return svae_conv_fwd_split_stats(d, x, wsplit, bias, y, accumulate, pieces, nullptr, stream);
+}
+
+extern "C" int svae_conv_fwd_split_stats(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias, float* y,
+                                         int accumulate, int pieces, float* bn_part, void* stream) {
   if (int e = validate(d)) return e;
   SVAE_REQUIRE(x && wsplit && y, SVAE_ERR_ARG, "conv_fwd_split: null pointer");
   SVAE_REQUIRE(aligned16(x) && aligned16(wsplit) && aligned16(y), SVAE_ERR_ALIGN, "conv_fwd_split: pointers must be 16-byte aligned");
@@ -1317,6 +1336,7 @@ extern "C" int svae_conv_fwd_split(const svae_conv_desc* d, const float* x, cons
   g.Kc = d->c_in; g.ldA = d->ld_in; g.ldC = d->ld_out;
   g.N = d->c_out;
   g.accumulate = accumulate;
+  g.stats = bn_part;
   build_plan(g, d, /*strided=*/!d->transposed, d->l_out, d->l_in);
   return launch_split_gather(sa, (hipStream_t)stream, d->tile[0], pieces);
 }

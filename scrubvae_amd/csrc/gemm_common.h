@@ -26,6 +26,8 @@ struct GatherArgs {
   // [z*nk/ksplit, (z+1)*nk/ksplit) and writes its partial tile to slab[z][m][N]; splitk_reduce adds them in z order
   int ksplit;
   float* slab;
+  // split-bf16 gather kernels: per-row-tile BatchNorm statistics of the written values, [row tiles][2][N] (NULL: off)
+  float* stats;
 };
 
 inline int validate(const svae_conv_desc* d) {

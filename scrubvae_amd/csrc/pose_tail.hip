@@ -512,7 +512,8 @@ extern "C" int svae_pose_tail(const float* y, int ld, const float* offsets, cons
   SVAE_REQUIRE(smem <= 160 * 1024, SVAE_ERR_SHAPE, "pose_tail: LDS tile %zu B exceeds 160 KiB", smem);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)pose_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e = hipFuncSetAttribute((const void*)pose_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SVAE_REQUIRE(e == hipSuccess, SVAE_ERR_LAUNCH, "pose_tail: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
     attr_set = true;
   }
   hipLaunchKernelGGL(pose_tail_kernel, dim3(svae_tail_blocks(rows)), dim3(64 * n_waves), smem, (hipStream_t)stream, g);

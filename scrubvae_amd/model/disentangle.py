@@ -3,8 +3,9 @@
 Module tree and state_dict names follow the reference (``reversal.1.mlp1.0.weight`` ...);
 the arithmetic runs in libscrubvae_hip.so through ``EnsembleRunner``: every Linear is the
 MFMA implicit-GEMM kernel (a 1x1 "conv"), ReLU / losses are the HIP row kernels.
-Streaming closed-form scrubbers (MovingAvgLeastSquares, QDA, ...) are
-outside this round's scope.
+The streaming closed-form scrubbers of SURVEY 8a row A2 (MovingAvgLeastSquares, MovingAverageFilter,
+QuadraticDiscriminantFilter, LinearProjection, MutInfoEstimator) follow below, behind the reference's
+API, on device tensor ops that seed the HIP backward.
 """
 from __future__ import annotations
 
@@ -73,7 +74,9 @@ class AdvNetScrubber(nn.Module):
 
 
 class EnsembleRunner:
-    """Forward/backward of one MLPEnsemble for a fixed number of rows on the HIP kernels."""
+    """Forward/backward of one MLPEnsemble for a fixed number of rows, Linear by Linear on the GEMM kernels (ensembles too
+    wide for the fused kernels of FusedEnsembleRunner)."""
+    fused = False
 
     def __init__(self, ens: MLPEnsemble, rows: int, device):
         self.ens, self.rows = ens, rows
@@ -127,6 +130,107 @@ class EnsembleRunner:
                     ops.relu_bwd(prev["g"], prev["act"], prev["g"])
                     g = prev["g"]
         return self.g_in
+
+
+class FusedEnsembleRunner:
+    """One MLPEnsemble for a fixed batch on the fused kernels of csrc/ensemble.hip: ONE launch forward (all four members, the
+    input assembled in the kernel) and one backward launch plus a fixed-order reduction (weight / bias gradients, input
+    gradient summed over the members and added to the latent seed with the gradient-reversal coefficient).
+
+    halves = 1: rows = batch, input = src0[:, :n0] (GRScrubber: mu, or the `linear` method's z_null).
+    halves = 2: rows = 2 * batch, input = cat(src0[:, :n0], src1) with column `shuf_col` of src1 taken from row perm[b] in the
+    second copy (AdvNetScrubber on cat([mu;mu],[v;v_shuffle]), disentangle.py:678-684)."""
+
+    fused = True
+
+    def __init__(self, ens: MLPEnsemble, batch: int, device, halves=1):
+        from .. import _lib
+        self.ens, self.batch, self.halves, self.rows = ens, batch, halves, batch * halves
+        self.in_p = pad16(ens.in_dim)
+        self.out_p = pad16(ens.out_dim)
+        self.lins = [[m for m in mlp if isinstance(m, LinearP)] for mlp in ens.members()]
+        if len(self.lins) > _lib.ENS_MEMBERS or any(len(l) > _lib.ENS_MAX_LAYERS for l in self.lins):
+            raise ValueError("ensemble shape outside the fused kernel's limits")
+        self.outs = [torch.zeros(self.rows, self.out_p, device=device) for _ in self.lins]
+        self.d_outs = [torch.zeros(self.rows, self.out_p, device=device) for _ in self.lins]
+        self.gx_raw = None
+        self.ws = None
+        self.desc = _lib.EnsDesc()
+        self._fill_static()
+
+    def _fill_static(self):
+        d = self.desc
+        d.n_members = len(self.lins)
+        d.batch, d.halves = self.batch, self.halves
+        for mi, lins in enumerate(self.lins):
+            m = d.member[mi]
+            m.n_layers = len(lins)
+            m.out, m.d_out = self.outs[mi].data_ptr(), self.d_outs[mi].data_ptr()
+            for li, lin in enumerate(lins):
+                L = m.layer[li]
+                L.w, L.b = lin.weight.data_ptr(), lin.bias.data_ptr()
+                L.K, L.N = lin.in_lib, lin.out_lib
+
+    def fits(self):
+        """whether the fused kernels accept this ensemble (its activations fit one workgroup's LDS)"""
+        d = self.desc
+        d.src0, d.ld0, d.n0 = self.outs[0].data_ptr(), self.in_p, min(self.ens.in_dim, self.in_p)  # placeholders for the check
+        d.src1, d.ld1, d.n1, d.perm, d.shuf_col = None, 0, 0, None, 0
+        keep = d.halves
+        d.halves = 1
+        ok = ops.ens_bwd_workspace(d) > 0
+        d.halves = keep
+        return ok
+
+    def _bind(self, src0, n0, src1=None, perm=None, shuf_col=0, param_grads=False, shuf_vals=None):
+        d = self.desc
+        d.shuf_vals = None if shuf_vals is None else shuf_vals.data_ptr()
+        d.src0, d.ld0, d.n0 = src0.data_ptr(), src0.shape[1], n0
+        if src1 is not None:
+            d.src1, d.ld1, d.n1 = src1.data_ptr(), src1.shape[1], src1.shape[1]
+        else:
+            d.src1, d.ld1, d.n1 = None, 0, 0
+        d.perm, d.shuf_col = (None if perm is None else perm.data_ptr()), int(shuf_col)
+        for mi, lins in enumerate(self.lins):
+            for li, lin in enumerate(lins):
+                L = d.member[mi].layer[li]
+                L.w, L.b = lin.weight.data_ptr(), lin.bias.data_ptr()
+                g = param_grads and lin.weight.grad is not None
+                L.dw = lin.weight.grad.data_ptr() if g else None
+                L.db = lin.bias.grad.data_ptr() if g else None
+
+    def forward(self, src0, n0, src1=None, perm=None, shuf_col=0, shuf_vals=None):
+        """-> list of 4 pre-activation outputs [rows, out_p].  halves = 2: give `perm` (int64 [batch], local rows of src1) or
+        `shuf_vals` (fp32 [batch], the shuffled column's values themselves)."""
+        for t in (src0, src1, shuf_vals):
+            ops._f32c(t, "ensemble input")
+        if perm is not None and not (perm.is_cuda and perm.dtype == torch.int64 and perm.is_contiguous()):
+            raise ValueError("perm: contiguous int64 CUDA tensor expected")
+        self._inputs = (src0, n0, src1, perm, shuf_col, shuf_vals)
+        self._bind(src0, n0, src1, perm, shuf_col, shuf_vals=shuf_vals)
+        ops.ens_fwd(self.desc)
+        return self.outs
+
+    def backward(self, d_src0, coef, param_grads=True, accumulate=False, want_raw=False):
+        """Gradients of sum_m <d_outs[m], out_m>: parameter gradients into the Linear layers' .grad (unless frozen), and
+        d_src0[:, :n0] += coef * (input gradient summed over members and halves).  want_raw: also return the un-scaled input
+        gradient [rows, in_p] (the `linear` method chains it through its projection)."""
+        src0, n0, src1, perm, shuf_col, shuf_vals = self._inputs
+        self._bind(src0, n0, src1, perm, shuf_col, param_grads=param_grads, shuf_vals=shuf_vals)
+        if self.ws is None:
+            self.ws = torch.empty(ops.ens_bwd_workspace(self.desc) // 4 + 64, device=src0.device)
+        need = ops.ens_bwd_workspace(self.desc)
+        if need == 0:
+            raise RuntimeError("ens_bwd: descriptor rejected: " + __import__("scrubvae_amd")._lib.last_error())
+        if self.ws.numel() * 4 < need:
+            self.ws = torch.empty(need // 4 + 64, device=src0.device)
+        raw = None
+        if want_raw:
+            if self.gx_raw is None:
+                self.gx_raw = torch.zeros(self.rows, self.in_p, device=src0.device)
+            raw = self.gx_raw
+        ops.ens_bwd(self.desc, d_src0, 0 if d_src0 is None else d_src0.shape[1], coef, raw, self.ws, accumulate)
+        return raw
 
 
 class MovingAvgLeastSquares(nn.Module):

@@ -26,7 +26,7 @@ from .. import ops
 from ..ops import pad16
 from .._lib import make_tree
 from .layers import ConvP, LinearP, BatchNormP, PReLUP, Marker, Leaf, make_activation, slope_grad
-from .disentangle import GRScrubber, AdvNetScrubber, MLPEnsemble, EnsembleRunner
+from .disentangle import GRScrubber, AdvNetScrubber, MLPEnsemble, EnsembleRunner, FusedEnsembleRunner
 
 
 def find_latent_dim(window_size, kernel, num_layers, dilation=None):
@@ -177,6 +177,7 @@ class ResVAE(nn.Module):
         self.world_size, self.rank, self.process_group = 1, 0, None
         self.bucket_min_bytes = 4 << 20  # smallest encoder gradient bucket worth its own all-reduce (xGMI: few, large)
         self.sync_bn = True
+        self.shuffle_seed, self._shuffle_draws = 0, 0  # shared-seed global permutation of the adversarial shuffle (N > 1)
         # training fast path: skip the forward-time tail launch; data_o["x6d"/"root"] are then
         # only valid after get_batch_loss (which runs the fused tail once).  Off by default.
         self.defer_tail = False
@@ -234,6 +235,18 @@ class ResVAE(nn.Module):
             # inside a block the order is residual.0-3, skip, add.0-1: everything from residual.3 on is final as soon as the
             # second BatchNorm's backward and the two weight gradients that read its output gradient are queued
             self._enc_mid_cuts.append(min(off for m, pname, shape, off, numel in slots if m is blk.residual[3]))
+        # contiguous [lo, hi) element ranges of the flat buffers that hold TRAINABLE parameters: the optimizer, like torch's,
+        # only touches those (the AdvNetScrubber ensemble is frozen, disentangle.py:670-671 -- AdamW must not decay it)
+        spans = []
+        for m, pname, shape, off, numel in slots:
+            if id(m) in frozen:
+                continue
+            end = off + (numel + 3) // 4 * 4
+            if spans and spans[-1][1] == off:
+                spans[-1][1] = end
+            else:
+                spans.append([off, end])
+        self.trainable_spans = [tuple(s) for s in spans]
         self.to(device)  # buffers
         self._assign_grad_views()
 
@@ -311,6 +324,7 @@ class ResVAE(nn.Module):
         the split-bf16 weight copies of every conv seen so far are refreshed in one launch (convs met for
         the first time in this pass split lazily at their first use)."""
         self.__dict__["_main"] = None
+        ops.check_current_device(self.device)
         ops.bump_weight_epoch()
         if self._split_users:
             ops.split_weights_batched([(c, p.weight) for c, p in self._split_users.values()])
@@ -360,11 +374,11 @@ class ResVAE(nn.Module):
         side.wait_event(ev)
         if ops.TIMER is None:
             # the bodies forked here are C-ABI launches only: point them at the side stream directly
-            ops.STREAM_OVERRIDE = side.cuda_stream
+            ops._TLS.stream_override = side.cuda_stream
             try:
                 fn()
             finally:
-                ops.STREAM_OVERRIDE = None
+                ops._TLS.stream_override = None
         else:  # the launch timer records torch events on torch's current stream
             with torch.cuda.stream(side):
                 fn()
@@ -407,6 +421,28 @@ class ResVAE(nn.Module):
             return dist.all_reduce(t, group=self.process_group, async_op=async_op)
         return None
 
+    def _allgather(self, t):
+        """Concatenation of the ranks' 1-D tensors `t` in rank order (same length on every rank)."""
+        if self.world_size == 1:
+            return t
+        import torch.distributed as dist
+        if t.is_cuda and dist.get_backend(self.process_group) == "gloo":  # test configuration: stage through the host
+            h = t.detach().cpu()
+            out = torch.empty(self.world_size * h.numel(), dtype=h.dtype)
+            dist.all_gather_into_tensor(out, h, group=self.process_group)
+            return out.to(t.device)
+        out = torch.empty(self.world_size * t.numel(), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.process_group)
+        return out
+
+    def global_permutation(self, n):
+        """The adversarial shuffle's permutation of the GLOBAL batch (AdvNetScrubber.shuffle, disentangle.py:678-684) under data
+        parallelism: drawn on the host from a generator every rank seeds identically (shuffle_seed, advanced per draw), so all
+        ranks hold the same permutation without a broadcast."""
+        g = torch.Generator().manual_seed(int(self.shuffle_seed) * 1000003 + self._shuffle_draws)
+        self._shuffle_draws += 1
+        return torch.randperm(n, generator=g)
+
     def _bucket_allreduce(self, lo, hi, acc):
         """Data-parallel gradient bucket: flat_grads[lo:hi] is final once everything queued so far on the main and side
         streams has run.  The all-reduce is fed from its own stream, which waits for those streams -- the main chain
@@ -428,15 +464,32 @@ class ResVAE(nn.Module):
             return dist.all_reduce(t, group=self.process_group, async_op=True)
 
     # ------------------------------------------------------------------ BN + PReLU stage
-    def _bn_act(self, tag, x, bn: BatchNormP, act: PReLUP, rows, out):
+    def _conv_fwd_bn(self, cv, x, p, y, accumulate=False):
+        """Conv forward whose output feeds a train-mode BatchNorm: where the conv runs a split-bf16 kernel the per-tile
+        (sum, sum of squares) of the output come out of the GEMM epilogue.  Returns (part [tiles, 2, Cp], tiles) for _bn_act,
+        or None (eval mode / fp32 kernel: _bn_act makes its own statistics pass)."""
+        if self.training:
+            cv.tune_fwd(x, p.weight, p.bias)
+            n = cv.stats_tiles()
+            if n > 0:
+                part = self._buf(f"bn.tpart.{n}.{cv.c_out_p}", (n, 2, cv.c_out_p))
+                cv.fwd(x, p.weight, p.bias, y, accumulate=accumulate, stats=part)
+                return part, n
+        cv.fwd(x, p.weight, p.bias, y, accumulate=accumulate)
+        return None
+
+    def _bn_act(self, tag, x, bn: BatchNormP, act: PReLUP, rows, out, stats=None):
         Cp = pad16(bn.c)
         scale, shift = self._buf(tag + ".scale", (Cp,)), self._buf(tag + ".shift", (Cp,))
         if self.training:
-            nch = ops.bn_chunks(rows)
-            part = self._buf(f"bn.part.{nch}.{Cp}", (nch, 2, Cp))
             sums = self._buf(tag + ".sums", (2, Cp))
             mean, rstd = self._buf(tag + ".mean", (Cp,)), self._buf(tag + ".rstd", (Cp,))
-            ops.bn_stats_partial(x, rows, Cp, Cp, part)
+            if stats is not None:  # statistics came out of the producing GEMM's epilogue
+                part, nch = stats
+            else:
+                nch = ops.bn_chunks(rows)
+                part = self._buf(f"bn.part.{nch}.{Cp}", (nch, 2, Cp))
+                ops.bn_stats_partial(x, rows, Cp, Cp, part)
             if self.world_size > 1 and self.sync_bn:
                 ops.bn_reduce_partials(part, nch, Cp, sums)
                 self._allreduce(sums)
@@ -526,13 +579,13 @@ class ResVAE(nn.Module):
             cvs = self._conv(t + ".sk", blk.skip, B, L)
             self._fork(lambda: cvs.fwd(a, blk.skip.weight, blk.skip.bias, s))
             r0 = self._buf(t + ".r0", (B * Lo, cv0.c_out_p))
-            cv0.fwd(a, conv0.weight, conv0.bias, r0)
+            st1 = self._conv_fwd_bn(cv0, a, conv0, r0)
             r0a = self._buf(t + ".r0a", (B * Lo, cv0.c_out_p))
-            self._bn_act(t + ".bn1", r0, bn1, act1, B * Lo, r0a)
+            self._bn_act(t + ".bn1", r0, bn1, act1, B * Lo, r0a, st1)
             self._join_side(1)
-            cv3.fwd(r0a, conv3.weight, conv3.bias, s, accumulate=True)
+            st2 = self._conv_fwd_bn(cv3, r0a, conv3, s, accumulate=True)  # statistics of skip + residual: the sum is what it writes
             a2 = self._buf(t + ".a", (B * Lo, cv3.c_out_p))
-            self._bn_act(t + ".bn2", s, blk.add[0], blk.add[1], B * Lo, a2)
+            self._bn_act(t + ".bn2", s, blk.add[0], blk.add[1], B * Lo, a2, st2)
             a, L = a2, Lo
         if L != enc.latent_len:
             raise ValueError(f"encoder output length {L} != find_latent_dim {enc.latent_len} (reference would fail too)")
@@ -600,13 +653,13 @@ class ResVAE(nn.Module):
 
             self._fork(skip_branch)  # upsample + skip conv on the side stream
             t0 = self._buf(t + ".t0", (B * L, cv1.c_out_p))
-            cv1.fwd(d, ct1.weight, ct1.bias, t0)
+            st1 = self._conv_fwd_bn(cv1, d, ct1, t0)
             t0a = self._buf(t + ".t0a", (B * L, cv1.c_out_p))
-            self._bn_act(t + ".bn1", t0, bn1, act1, B * L, t0a)
+            self._bn_act(t + ".bn1", t0, bn1, act1, B * L, t0a, st1)
             self._join_side(1)
-            cv2.fwd(t0a, ct2.weight, ct2.bias, s, accumulate=True)
+            st2 = self._conv_fwd_bn(cv2, t0a, ct2, s, accumulate=True)
             d2 = self._buf(t + ".a", (B * Lo, cv2.c_out_p))
-            self._bn_act(t + ".bn2", s, blk.add[0], blk.add[1], B * Lo, d2)
+            self._bn_act(t + ".bn2", s, blk.add[0], blk.add[1], B * Lo, d2, st2)
             d, L = d2, Lo
         cvo = self._conv("dec.out", dec.conv_out, B, L)
         if cvo.l_out != self.window:
@@ -717,13 +770,20 @@ class ResVAE(nn.Module):
             data_o["disentangle"][method] = {}
             for k, m in module_dict.items():
                 if method == "grad_reversal":
-                    outs = self._runner(method, k, m.ensemble, B).forward(latent(k))
+                    r = self._runner(method, k, m.ensemble, B)
+                    outs = r.forward(latent(k), self.z_dim) if r.fused else r.forward(latent(k))
                     data_o["disentangle"][method][k] = [o[:, : m.ensemble.out_dim] for o in outs]
                 elif method == "adversarial_net":
-                    x = self._buf(f"an.{k}.x0", (B, pad16(m.ensemble.in_dim)), zero=True)
-                    x[:, : self.z_dim] = latent(k)[:, : self.z_dim]
-                    x[:, self.z_dim: self.z_dim + self.conditional_dim] = data_o["var"]
-                    outs = self._runner(method + ".fwd", k, m.ensemble, B).forward(x)
+                    # the un-shuffled evaluation on (mu, var) that VAE.forward stores (residual.py:357-358); the loss recomputes
+                    # it with the shuffle
+                    r = self._runner(method + ".fwd", k, m.ensemble, B)
+                    if r.fused:
+                        outs = r.forward(latent(k), self.z_dim, src1=self._var32(data_o["var"]))
+                    else:
+                        x = self._buf(f"an.{k}.x0", (B, pad16(m.ensemble.in_dim)), zero=True)
+                        x[:, : self.z_dim] = latent(k)[:, : self.z_dim]
+                        x[:, self.z_dim: self.z_dim + self.conditional_dim] = data_o["var"]
+                        outs = r.forward(x)
                     data_o["disentangle"][method][k] = [torch.softmax(o[:, :2], -1) for o in outs]
                 elif method == "moving_avg_lsq":
                     data_o["disentangle"][method][k] = m(latent(k)[:, : self.z_dim])
@@ -734,11 +794,24 @@ class ResVAE(nn.Module):
         self._state = dict(B=B, flat=flat, h=h, eps=eps, mu=mu, sigma=sigma, zc=zc, klp=klp, data=data, lin=lin)
         return data_o
 
-    def _runner(self, method, key, ens: MLPEnsemble, rows):
-        k = (method, key, rows)
+    def _var32(self, var):
+        """conditional variables as the contiguous fp32 [B, D] array the ensemble kernels read"""
+        return var if (var.dtype == torch.float32 and var.is_contiguous()) else var.float().contiguous()
+
+    def _runner(self, method, key, ens: MLPEnsemble, batch, halves=1):
+        """Runner of one ensemble for `batch` samples (halves = 2: the adversarial net's doubled batch).  The fused kernels
+        (csrc/ensemble.hip) take every ensemble whose activations fit a workgroup's LDS; wider ones (z_dim >~ 64) run Linear
+        by Linear on the GEMM kernels."""
+        k = (method, key, batch, halves)
         r = self._runners.get(k)
         if r is None:
-            r = EnsembleRunner(ens, rows, self.device)
+            r = None
+            if ops.FUSED_ENSEMBLE:
+                cand = FusedEnsembleRunner(ens, batch, self.device, halves)
+                if cand.fits():
+                    r = cand
+            if r is None:
+                r = EnsembleRunner(ens, batch * halves, self.device)
             self._runners[k] = r
         return r
 
@@ -773,6 +846,19 @@ class ResVAE(nn.Module):
             p.grad.add_(g)
         for item in pend["scrub"]:
             runner, d_outs, kind = item["runner"], item["d_outs"], item["kind"]
+            if runner.fused:  # one launch + a fixed-order reduction; the latent seed is updated by the kernel
+                if kind == "gr" and item.get("lin") is not None:  # head input was z_null(mu, W): chain through the projection
+                    g_in = runner.backward(None, 0.0, param_grads=True, accumulate=acc, want_raw=True)
+                    z_null, leaves = item["lin"]
+                    gs = torch.autograd.grad(z_null, leaves, grad_outputs=-item["alpha"] * g_in[:, : self.z_dim], retain_graph=True)
+                    d_mu[:, : self.z_dim] += gs[0]
+                    for p, g in zip(leaves[1:], gs[1:]):
+                        p.grad.add_(g)
+                elif kind == "gr":
+                    runner.backward(d_mu, -item["alpha"], param_grads=True, accumulate=acc)  # gradient reversal: -alpha * grad
+                else:  # adversarial net on cat([mu;mu],[v;v_shuffle]): both halves feed mu; its parameters are frozen
+                    runner.backward(d_mu, 1.0, param_grads=False)
+                continue
             g_in = runner.backward(d_outs, param_grads=(kind == "gr"), accumulate=acc)
             if kind == "gr" and item.get("lin") is not None:  # head input was z_null(mu, W): chain through the projection
                 z_null, leaves = item["lin"]

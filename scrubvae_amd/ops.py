@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import threading
 
 import torch
 
@@ -31,29 +32,40 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 def _stream():
     """hipStream_t of torch's current stream.  torch.cuda.current_stream() costs ~8 us per call (about 1 ms per
     optimizer step over ~120 calls); the raw-handle query is ~20x cheaper."""
-    if STREAM_OVERRIDE is not None:
-        return STREAM_OVERRIDE
+    o = _TLS.stream_override
+    if o is not None:
+        return o
     if _raw_stream is not None:
         return _raw_stream(_device_index())
     return torch.cuda.current_stream().cuda_stream
 
 
-# hipStream_t every launch of this module goes to instead of torch's current stream (None: follow torch).  Set by
+# _TLS.stream_override: hipStream_t every launch of this module goes to instead of torch's current stream (None: follow torch).  Set by
 # ResVAE._fork around a side-stream body that consists of C-ABI launches only: entering / leaving a `torch.cuda.stream`
 # context costs ~15 us of Python per fork (~0.6 ms per optimizer step over ~40 forks).
-STREAM_OVERRIDE = None
+class _ThreadState(threading.local):
+    stream_override = None
 
 
-_DEVICE_INDEX = None
+_TLS = _ThreadState()  # per thread: two models driven from different threads do not see each other's side streams
+
+
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def _device_index():
-    """torch.cuda.current_device(), queried once per process (one process drives one GPU: parallel.init_distributed /
-    bench.py select the device before the first kernel launch)."""
-    global _DEVICE_INDEX
-    if _DEVICE_INDEX is None:
-        _DEVICE_INDEX = torch.cuda.current_device()
-    return _DEVICE_INDEX
+    """Index of torch's current device (the raw query is ~0.2 us: not cached, so a process that drives several devices
+    always launches on the stream of the device it has made current; ResVAE checks at the start of every pass that this
+    is the device its buffers live on)."""
+    return _get_device() if _get_device is not None else torch.cuda.current_device()
+
+
+def check_current_device(device):
+    """Raise if `device` (where a model's buffers live) is not torch's current device: the C ABI launches on the current
+    device's stream, so a mismatch would run kernels on the wrong GPU's stream."""
+    if device.type == "cuda" and device.index is not None and device.index != _device_index():
+        raise RuntimeError(f"model lives on cuda:{device.index} but the current device is cuda:{_device_index()}: wrap the call in "
+                           f"torch.cuda.device({device.index})")
 
 
 def _f32c(t, name="tensor"):
@@ -100,7 +112,9 @@ _TABLE_PATH = os.environ.get("SVAE_TILE_TABLE") or os.path.join(os.path.dirname(
 try:
     with open(_TABLE_PATH) as _f:
         TILE_TABLE = json.load(_f)
-except (OSError, ValueError):
+except (OSError, ValueError) as _e:  # still correct (geometries are tuned on first use) but not the benchmarked kernel mix: say so
+    import warnings
+    warnings.warn(f"scrubvae_amd: tile table {_TABLE_PATH} unreadable ({_e}); every geometry will be tuned on first use")
     TILE_TABLE = {}
 TUNED_LOG = {}  # geometry key -> code chosen in this process (dumped by tools/tune_tiles.py)
 _TILES = (128128, 128064, 64128, 64064)
@@ -140,6 +154,7 @@ _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2
 # 1BBBNNN: single LDS buffer; 256-edge tiles: 8 waves, half the operand bytes per FLOP through the vector-memory path
 _WGRAD_BIG = (256256, 256128, 128256)
 _SPLIT_WGRAD_CODES = _TILES + tuple(1000000 + c for c in _TILES) + _WGRAD_BIG + tuple(1000000 + c for c in _WGRAD_BIG)
+FUSE_BN_STATS = True  # BatchNorm batch statistics from the conv GEMM's epilogue where its kernel supports it
 MIX_F32 = True  # a bf16x6 conv may keep the fp32 MFMA kernel for a pass where that is faster (same accuracy)
 WEIGHT_EPOCH = 0  # bumped whenever master weights may have changed (start of every model pass)
 
@@ -238,6 +253,7 @@ class Conv:
         self.desc.tile[_KIND_ID[kind]] = code
         self._ws_bytes = None
         self.__dict__.pop("_names", None)
+        self.__dict__.pop("_stats_tiles", None)
 
     def _tune(self, kind, run):
         """run(): launches this conv once with scratch outputs.  Picks the kernel family (for a
@@ -246,14 +262,13 @@ class Conv:
         if kind in tuned:
             return
         tuned.add(kind)
-        global STREAM_OVERRIDE
-        if STREAM_OVERRIDE is not None:  # the timing events below live on torch's current stream: tune there
-            keep, STREAM_OVERRIDE = STREAM_OVERRIDE, None
+        if _TLS.stream_override is not None:  # the timing events below live on torch's current stream: tune there
+            keep, _TLS.stream_override = _TLS.stream_override, None
             try:
                 tuned.discard(kind)
                 return self._tune(kind, run)
             finally:
-                STREAM_OVERRIDE = keep
+                _TLS.stream_override = keep
         d = self.desc
         base = self._base_pieces(kind)
         key = f"{kind}{'@' + str(base) if base else ''}:{d.batch}:{d.l_in}:{d.c_in}:{d.c_out}:{d.ld_in}:{d.ld_out}:{d.kernel}:{d.stride}:{d.padding}:{d.transposed}"
@@ -273,8 +288,10 @@ class Conv:
             self._set_choice(kind, pieces, code)
             try:
                 run()  # warm-up (also validates the workspace size for this tile)
-            except RuntimeError:
-                continue
+            except _lib.SvaeError as e:
+                if e.status in (_lib.ERR_SHAPE, _lib.ERR_WORKSPACE):  # this tile does not exist for this geometry: not a candidate
+                    continue
+                raise  # a launch failure or a bad argument is a bug, not a tuning outcome
             t = float("inf")
             for _ in range(AUTOTUNE_REPS):  # min of several single-launch timings: robust against one-off stalls
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -344,11 +361,24 @@ class Conv:
             cache[kind_id] = torch.empty(n // 4 + 16, device=device) if n > 0 else None
         return cache[kind_id]
 
-    def _launch_fwd(self, x, w, bias, y, acc):
+    def stats_tiles(self):
+        """Row tiles of the forward launch when its kernel can emit the BatchNorm statistics of its output from the epilogue
+        (the split-bf16 gather kernels), else 0 (fp32 kernels: the caller runs bn_stats_partial).  Valid once the tile
+        choice is fixed (tune_fwd)."""
+        if not FUSE_BN_STATS or not self._kind_pieces("fwd") or "fwd" not in self.__dict__.get("_tuned", ()):
+            return 0
+        n = self.__dict__.get("_stats_tiles")
+        if n is None:
+            n = self.__dict__["_stats_tiles"] = int(_lib.lib().svae_conv_fwd_stats_tiles(C.byref(self.desc)))
+        return n
+
+    def _launch_fwd(self, x, w, bias, y, acc, stats=None):
         kp = self._kind_pieces("fwd")
         if kp:
-            return check(_lib.lib().svae_conv_fwd_split(C.byref(self.desc), _p(x), _p(self.split_weights(w)), _p(bias), _p(y),
-                                                         acc, kp, _stream()), "conv_fwd_split")
+            return check(_lib.lib().svae_conv_fwd_split_stats(C.byref(self.desc), _p(x), _p(self.split_weights(w)), _p(bias), _p(y),
+                                                               acc, kp, _p(stats), _stream()), "conv_fwd_split")
+        if stats is not None:
+            raise RuntimeError("conv_fwd: fused BatchNorm statistics need a split-bf16 forward kernel (check stats_tiles())")
         ws = self._splitk_ws(0, x.device)
         if ws is not None:
             return check(_lib.lib().svae_conv_fwd_ws(C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), acc, _p(ws), ws.numel() * 4,
@@ -375,11 +405,16 @@ class Conv:
         return check(_lib.lib().svae_conv_wgrad(C.byref(self.desc), _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, acc,
                                                  _stream()), "conv_wgrad")
 
-    def fwd(self, x, w, bias, y, accumulate=False):
+    def tune_fwd(self, x, w, bias):
+        """Fix the forward kernel / tile of this geometry (table lookup or first-use timing on scratch outputs)."""
         if "fwd" not in self.__dict__.get("_tuned", ()):
             scratch = torch.empty(self.batch * self.l_out * self.desc.ld_out + 16, device=x.device)
             self._tune("fwd", lambda: self._launch_fwd(x, w, bias, scratch, 0))
-        _timed("fwd", self, self.c_out_p, lambda: self._launch_fwd(x, w, bias, y, int(accumulate)))
+
+    def fwd(self, x, w, bias, y, accumulate=False, stats=None):
+        """stats: [stats_tiles()][2][c_out_p] buffer for the fused BatchNorm statistics of y (None: off)"""
+        self.tune_fwd(x, w, bias)
+        _timed("fwd", self, self.c_out_p, lambda: self._launch_fwd(x, w, bias, y, int(accumulate), stats))
         return y
 
     def dgrad(self, dy, w, dx, accumulate=False):
@@ -610,6 +645,14 @@ def adam_step_dev(p, g, m, v, hyper, beta1, beta2, eps, weight_decay, decoupled,
                                         int(decoupled), grad_scale, _stream()), "adam_step_dev")
 
 
+def adam_advance(hyper, beta1, beta2):
+    check(_lib.lib().svae_adam_advance(_p(hyper), beta1, beta2, _stream()), "adam_advance")
+
+
+def clip_grads(g, sumsq, max_norm):
+    check(_lib.lib().svae_clip_grads(_p(g), g.numel(), _p(sumsq), float(max_norm), _stream()), "clip_grads")
+
+
 def sumsq_blocks(n):
     return int(_lib.lib().svae_sumsq_blocks(n))
 
@@ -652,3 +695,30 @@ def ce_sum(logits, ld, labels, rows, Cn, scale, part, dlogits):
 
 def double_softmax_ce_sum(logits, ld, rows, scale, part, dlogits):
     check(_lib.lib().svae_double_softmax_ce_sum(_p(logits), ld, rows, float(scale), _p(part), _p(dlogits), _stream()), "double_softmax_ce_sum")
+
+
+# ------------------------------------------------------------------- fused MLP ensembles
+FUSED_ENSEMBLE = True  # False: every ensemble Linear by Linear on the GEMM kernels (the path wide ensembles take anyway)
+
+
+def ens_fwd(desc):
+    check(_lib.lib().svae_ens_fwd(C.byref(desc), _stream()), "ens_fwd")
+
+
+def ens_bwd_workspace(desc):
+    return int(_lib.lib().svae_ens_bwd_workspace(C.byref(desc)))
+
+
+def ens_bwd(desc, d_src0, ld_d, coef, gx_raw, ws, accumulate):
+    check(_lib.lib().svae_ens_bwd(C.byref(desc), _p(d_src0), ld_d, float(coef), _p(gx_raw), _p(ws), ws.numel() * ws.element_size(),
+                                  int(accumulate), _stream()), "ens_bwd")
+
+
+def ens_loss(kind, outs, dpreds, loss_w, grad_s, target, ld_t, labels, rows, Cn, ld, part):
+    n = len(outs)
+    o = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
+    d = (C.c_void_p * n)(*[(None if t is None else t.data_ptr()) for t in dpreds])
+    lw = (C.c_float * n)(*[float(v) for v in loss_w])
+    gs = (C.c_float * n)(*[float(v) for v in grad_s])
+    check(_lib.lib().svae_ens_loss(int(kind), o, d, lw, gs, n, _p(target), int(ld_t), _p(labels), rows, Cn, ld, _p(part), _stream()),
+          "ens_loss")

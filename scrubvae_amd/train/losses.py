@@ -154,27 +154,39 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
             if method == "grad_reversal":
                 m = model.disentangle[method][key]
                 runner = model._runner(method, key, m.ensemble, B)
-                outs = [l[-1]["pre"] for l in runner.members]
+                outs = runner.outs if runner.fused else [l[-1]["pre"] for l in runner.members]
                 out_dim, out_p = m.ensemble.out_dim, pad16(m.ensemble.out_dim)
                 c = 4.0 * nk * Bg
                 weights = [c ** -4, c ** -3, c ** -2, c ** -1]  # normalisation inside the loop (losses.py:279-284)
                 lk = key + "_gr"
                 v = _scalar(model, lk)
-                v.zero_()
-                d_outs = []
                 nb_r = ops.rowloss_blocks(B)
-                for i, (o, w) in enumerate(zip(outs, weights)):
-                    part = model._buf(f"gr.part.{i}", (nb_r,))
-                    dpred = model._buf(f"gr.{key}.d{i}", (B, out_p), zero=True) if train else None
-                    sc = float(loss_scale[lk]) * w
+                if runner.fused:  # the four members' losses and seed gradients in one launch, one reduction
+                    part = model._buf("gr.part4", (4 * nb_r,))
+                    d_outs = runner.d_outs if train else [None] * 4
+                    gs = [float(loss_scale[lk]) * w for w in weights]
                     if key == "ids":
                         labels = data[key].to(model.device).ravel().int().contiguous()
-                        ops.ce_sum(o, out_p, labels, B, out_dim, sc, part, dpred)
+                        ops.ens_loss(1, outs, d_outs, weights, gs, None, 0, labels, B, out_dim, out_p, part)
                     else:
                         tgt = model._prep(data[key])
-                        ops.mse_sum(o, out_p, tgt, tgt.shape[-1], B, out_dim, sc, part, dpred)
-                    ops.reduce_rows(part, nb_r, 1, w, v, accumulate=True)
-                    d_outs.append(dpred)
+                        ops.ens_loss(0, outs, d_outs, weights, gs, tgt, tgt.shape[-1], None, B, out_dim, out_p, part)
+                    ops.reduce_rows(part, 4 * nb_r, 1, 1.0, v)
+                else:
+                    v.zero_()
+                    d_outs = []
+                    for i, (o, w) in enumerate(zip(outs, weights)):
+                        part = model._buf(f"gr.part.{i}", (nb_r,))
+                        dpred = model._buf(f"gr.{key}.d{i}", (B, out_p), zero=True) if train else None
+                        sc = float(loss_scale[lk]) * w
+                        if key == "ids":
+                            labels = data[key].to(model.device).ravel().int().contiguous()
+                            ops.ce_sum(o, out_p, labels, B, out_dim, sc, part, dpred)
+                        else:
+                            tgt = model._prep(data[key])
+                            ops.mse_sum(o, out_p, tgt, tgt.shape[-1], B, out_dim, sc, part, dpred)
+                        ops.reduce_rows(part, nb_r, 1, w, v, accumulate=True)
+                        d_outs.append(dpred)
                 batch_loss[lk] = v.view(()).clone()
                 add_total(lk, v)
                 if train and loss_scale[lk] != 0:
@@ -184,30 +196,49 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 m = model.disentangle[method][key]
                 v_ind = model.disentangle_keys.index(key)
                 var = data_o["var"]
-                perm = adv_perm[key].to(model.device) if adv_perm is not None else torch.randperm(B, device=model.device)
-                in_p = pad16(m.ensemble.in_dim)
-                x = model._buf(f"an.{key}.x", (2 * B, in_p), zero=True)
+                shuf_vals = None
+                if world > 1:
+                    # data parallel: ONE permutation of the GLOBAL batch (every rank draws the same one from the shared seed),
+                    # so that N ranks shuffle exactly like one rank at the global batch; the shuffled column's values come
+                    # from the other ranks through a [Bg] all-gather
+                    perm_g = adv_perm[key] if adv_perm is not None else model.global_permutation(Bg)
+                    col = model._allgather(var[:, v_ind].float().contiguous())
+                    shuf_vals = col[perm_g[model.rank * B: (model.rank + 1) * B].to(model.device)].contiguous()
+                    perm = None
+                else:
+                    perm = adv_perm[key].to(model.device) if adv_perm is not None else torch.randperm(B, device=model.device)
                 mu = st["mu"]
-                x[:B, :z] = mu[:, :z]
-                x[B:, :z] = mu[:, :z]
                 D = model.conditional_dim
-                x[:B, z: z + D] = var
-                x[B:, z: z + D] = var
-                x[B:, z + v_ind] = var[perm, v_ind]  # one COLUMN of var is shuffled (disentangle.py:680)
-                runner = model._runner(method, key, m.ensemble, 2 * B)
-                outs = runner.forward(x)
+                runner = model._runner(method, key, m.ensemble, B, halves=2)
                 lk = key + "_an"
                 vv = _scalar(model, lk)
-                vv.zero_()
                 nb_r = ops.rowloss_blocks(2 * B)
                 w = -1.0 / (4 * Bg)
-                d_outs = []
-                for i, o in enumerate(outs):
-                    part = model._buf(f"an.part.{i}", (nb_r,))
-                    dl = model._buf(f"an.{key}.d{i}", (2 * B, 16), zero=True) if train else None
-                    ops.double_softmax_ce_sum(o, 16, 2 * B, float(loss_scale[lk]) * w, part, dl)
-                    ops.reduce_rows(part, nb_r, 1, w, vv, accumulate=True)
-                    d_outs.append(dl)
+                if runner.fused:
+                    # cat([mu;mu], [v;v_shuffle]) is assembled inside the kernel: one COLUMN of var is shuffled (disentangle.py:680)
+                    outs = runner.forward(mu, z, src1=model._var32(var), perm=None if perm is None else perm.long().contiguous(),
+                                          shuf_col=v_ind, shuf_vals=shuf_vals)
+                    part = model._buf("an.part4", (4 * nb_r,))
+                    d_outs = runner.d_outs if train else [None] * 4
+                    ops.ens_loss(2, outs, d_outs, [w] * 4, [float(loss_scale[lk]) * w] * 4, None, 0, None, 2 * B, 2, 16, part)
+                    ops.reduce_rows(part, 4 * nb_r, 1, 1.0, vv)
+                else:
+                    in_p = pad16(m.ensemble.in_dim)
+                    x = model._buf(f"an.{key}.x", (2 * B, in_p), zero=True)
+                    x[:B, :z] = mu[:, :z]
+                    x[B:, :z] = mu[:, :z]
+                    x[:B, z: z + D] = var
+                    x[B:, z: z + D] = var
+                    x[B:, z + v_ind] = var[perm, v_ind] if shuf_vals is None else shuf_vals  # one COLUMN of var is shuffled (disentangle.py:680)
+                    outs = runner.forward(x)
+                    vv.zero_()
+                    d_outs = []
+                    for i, o in enumerate(outs):
+                        part = model._buf(f"an.part.{i}", (nb_r,))
+                        dl = model._buf(f"an.{key}.d{i}", (2 * B, 16), zero=True) if train else None
+                        ops.double_softmax_ce_sum(o, 16, 2 * B, float(loss_scale[lk]) * w, part, dl)
+                        ops.reduce_rows(part, nb_r, 1, w, vv, accumulate=True)
+                        d_outs.append(dl)
                 batch_loss[lk] = vv.view(()).clone()
                 add_total(lk, vv)
                 if train and loss_scale[lk] != 0:

@@ -47,8 +47,10 @@ def get_beta_schedule(schedule, beta):
 
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam / AdamW semantics (defaults: betas (0.9,0.999), eps 1e-8, weight decay
-    0 / 0.01; trainer.py:60-65) as ONE HIP launch over the model's flat parameter, gradient
-    and moment buffers.  ``param_groups[0]["lr"]`` is honoured, so torch LR schedulers work."""
+    0 / 0.01; trainer.py:60-65) as ONE HIP launch per contiguous span of trainable parameters in the
+    model's flat parameter, gradient and moment buffers (one span, or two around a frozen
+    AdvNetScrubber -- torch's optimizers skip parameters without a gradient, so must the weight
+    decay).  ``param_groups[0]["lr"]`` is honoured, so torch LR schedulers work."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
         self.model = model
@@ -58,38 +60,47 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(model.flat_params)
         self.step_count = 0
         self.grad_scale = 1.0
-        # device copy of the step-dependent scalars for hipGraph replays (see GraphedStep)
+        # device copy of the step-dependent scalars for hipGraph replays: {lr, lr/bc1, 1/sqrt(bc2), step}.  The step
+        # counter lives on the DEVICE and is advanced by a captured one-thread kernel; the host only writes lr, with a
+        # stream-ordered fill, when it changes -- replays queued ahead of the GPU cannot race a host buffer.
         self.hyper = torch.zeros(4, device=model.device)
-        self._hyper_host = torch.zeros(4).pin_memory() if torch.cuda.is_available() else torch.zeros(4)
+        self._dev_lr = None
+        self._dev_step = None
+
+    def _spans(self):
+        m = self.model
+        return [(m.flat_params[a:b], m.flat_grads[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b]) for a, b in m.trainable_spans]
 
     def refresh_hyper(self):
-        """Advance the step counter and push {lr, lr/bc1, 1/sqrt(bc2)} to the device (outside
-        any graph); the captured adam launch reads them from there."""
+        """Bookkeeping for one captured step (outside any graph): host step counter, and -- only when they changed --
+        the device copies of lr and of the step counter (after load_state_dict / eager steps in between)."""
         g = self.param_groups[0]
-        self.step_count += 1
-        b1, b2 = g["betas"]
         lr = float(torch.tensor(float(g["lr"]), dtype=torch.float32))  # the eager path passes lr as a C float
-        self._hyper_host[0] = lr
-        self._hyper_host[1] = lr / (1.0 - b1 ** self.step_count)
-        self._hyper_host[2] = 1.0 / math.sqrt(1.0 - b2 ** self.step_count)
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        if self._dev_lr != lr:
+            self.hyper[0:1].fill_(lr)
+            self._dev_lr = lr
+        if self._dev_step != self.step_count:
+            self.hyper[3:4].fill_(float(self.step_count))
+        self.step_count += 1
+        self._dev_step = self.step_count
 
     @torch.no_grad()
     def step_captured(self):
-        """The launch that goes INTO a graph: no host-side scalars."""
+        """The launches that go INTO a graph: no host-side scalars."""
         g = self.param_groups[0]
-        m = self.model
-        ops.adam_step_dev(m.flat_params, m.flat_grads, self.exp_avg, self.exp_avg_sq, self.hyper, g["betas"][0], g["betas"][1],
-                          g["eps"], g["weight_decay"], g["decoupled"], self.grad_scale)
+        ops.adam_advance(self.hyper, g["betas"][0], g["betas"][1])
+        for p, gr, m, v in self._spans():
+            ops.adam_step_dev(p, gr, m, v, self.hyper, g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], g["decoupled"],
+                              self.grad_scale)
 
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
         self.step_count += 1
-        m = self.model
-        m._assign_grad_views()
-        ops.adam_step(m.flat_params, m.flat_grads, self.exp_avg, self.exp_avg_sq, float(g["lr"]), g["betas"][0],
-                      g["betas"][1], g["eps"], g["weight_decay"], self.step_count, g["decoupled"], self.grad_scale)
+        self.model._assign_grad_views()
+        for p, gr, m, v in self._spans():
+            ops.adam_step(p, gr, m, v, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count,
+                          g["decoupled"], self.grad_scale)
 
     def zero_grad(self, set_to_none=True):
         pass  # gradients are overwritten by every backward
@@ -108,18 +119,18 @@ class FusedAdam(torch.optim.Optimizer):
 
 def clip_grad_norm_(model, max_norm=1e6):
     """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) on the flat gradient
-    buffer (trainer.py:164).  Returns the total norm as a device tensor.  With the
-    reference's max_norm=1e6 the clip never bites; if it does, the gradients are scaled."""
+    buffer (trainer.py:164): gradients *= min(1, max_norm / (norm + 1e-6)), decided on the device
+    (`svae_clip_grads` reads the squared norm and returns without touching the gradients when the
+    clip does not bite, which is always with the reference's max_norm=1e6 unless a step diverges).
+    Returns the total norm as a device tensor.  Frozen parameters have no gradient (their span of
+    the flat buffer stays zero)."""
     n = model.flat_grads.numel()
     part = model._buf("gn.part", (ops.sumsq_blocks(n),))
     out = model._buf("gn.out", (1,))
     ops.sumsq_partial(model.flat_grads, part)
     ops.reduce_rows(part, part.numel(), 1, 1.0, out)
-    norm = out.sqrt()
-    if max_norm < 1e5:  # only then can it matter in fp32 training; costs one tiny torch op
-        coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
-        model.flat_grads.mul_(coef)
-    return norm.view(())
+    ops.clip_grads(model.flat_grads, out, max_norm)
+    return out.sqrt().view(())
 
 
 def get_optimizer_and_lr_scheduler(model, train_config, load_path=None, start_epoch=None):
@@ -410,11 +421,8 @@ class GraphedStep:
         if not capture:  # same schedule launched eagerly (debugging / parity reference)
             return
         self.graph = torch.cuda.CUDAGraph()
-        optimizer.refresh_hyper()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph):  # capture does not execute: neither the host nor the device counter moves
             self.losses = self._body()
-        # the capture itself did not execute: undo the counter advance made for it
-        optimizer.step_count -= 1
 
     def _body(self):
         m = self.model

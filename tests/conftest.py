@@ -8,8 +8,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _usable_cpus():
+    """affinity mask capped by the cgroup CPU quota (the GPU boxes show all 256 host cores but give the job 16 CPUs)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    torch.set_num_threads(_usable_cpus())  # the CPU oracle's intra-op threads: more runnable threads than CPUs only throttle
 
 
 @pytest.fixture(scope="session")

@@ -20,8 +20,14 @@ def test_bench_defaults_match_baseline_config():
         a = bench.parse()
     finally:
         sys.argv = old
-    assert (a.gpus, a.batch, a.window, a.joints) == (1, 1024, 64, 23)      # BASELINE configs[1]
-    assert a.channel_list == [64, 128, 256, 512, 1024] and not a.full and not a.h2d and not a.graph
+    assert (a.gpus, a.batch, a.window, a.joints) == (1, 4096, 64, 23)      # BASELINE configs[2]: full SC-VAE, 4096 windows / GPU
+    assert a.channel_list == [64, 128, 256, 512, 1024] and a.full and not a.h2d and not a.graph and not a.no_secondary
+    sys.argv = ["bench.py", "--workload", "config1"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = old
+    assert (a.batch, a.full) == (1024, False)                              # BASELINE configs[1]
     assert a.precision in bench.PRODUCTS
 
 
@@ -43,4 +49,32 @@ def test_bench_prints_exactly_one_json_line_with_the_contract_fields():
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
-    assert cb["elbo_match"]["ok"] is True
+    assert cb["elbo_match"]["ok"] is True and cb["elbo_match"]["batch"] == 64   # checked at the timed batch
+    assert cb["threads"] == cb["cores"] and cb["host_cores"] >= cb["threads"]
+    assert "configs[2]" in d["config"]["workload"] and "secondary" not in d       # secondary only accompanies the default batch
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_full_config_sync_bn():
+    """bench.py's own N > 1 path -- the launch line the driver uses (torch.distributed.run, one process per rank), the FULL
+    configs[2] head set, --sync-bn, the shared-seed global adversarial shuffle, bucketed gradient all-reduce -- rehearsed with 2
+    gloo ranks on the one GPU of the test box (SVAE_DIST_BACKEND=gloo; on an 8-GPU node the same code runs over RCCL)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PYTHONPATH=ROOT, SVAE_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "64", "--sync-bn", "--no-roofline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2+syncbn"
+    assert "configs[2]" in d["config"]["workload"] and "cpu_baseline" not in d and "secondary" not in d
+    assert abs(d["value"] - 128 * 2 / (d["ms_per_step"] * 2e-3)) <= 0.01 * d["value"]
+    import math
+    assert math.isfinite(d["config"]["final_total_loss"])

@@ -22,13 +22,15 @@ def _free_port():
 
 
 ARENA = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
-METHODS = {"conditional": ["avg_speed_3d", "heading"], "grad_reversal": ["avg_speed_3d", "heading"]}
-LS = {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_gr": 1.0, "heading_gr": 2.0}
+METHODS = {"conditional": ["avg_speed_3d", "heading"], "grad_reversal": ["avg_speed_3d", "heading"], "adversarial_net": ["heading"]}
+LS = {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_gr": 1.0, "heading_gr": 2.0, "heading_an": 0.5}
+PERM = torch.randperm(16, generator=torch.Generator().manual_seed(9))  # the adversarial shuffle: ONE permutation of the global batch
 
 
-def _setup():
+def _setup(adv=True):
+    methods = dict(METHODS) if adv else {k: v for k, v in METHODS.items() if k != "adversarial_net"}
     cfg = O.OracleConfig(n_keypts=18, window=64, z_dim=8, kernel=5, channel=(16, 16, 16, 32, 32), diag=True, arena_size=ARENA,
-                         method=METHODS, features=["avg_speed_3d", "heading"], discrete_classes={"ids": torch.arange(4)})
+                         method=methods, features=["avg_speed_3d", "heading"], discrete_classes={"ids": torch.arange(4)})
     sd = O.init_state_dict(cfg, seed=4)
     data = O.synth_batch(cfg, 16, seed=4)
     eps = torch.randn(16, 8, generator=torch.Generator().manual_seed(1))
@@ -41,7 +43,7 @@ def _run(model, dis, data, eps, ls=LS):
     d = {k: v.cuda() for k, v in data.items()}
     d["eps"] = eps.cuda()
     data_o = model(d)
-    bl = get_batch_loss(model, d, data_o, ls, dis)
+    bl = get_batch_loss(model, d, data_o, ls, dis, adv_perm={"heading": PERM} if "heading_an" in ls else None)
     bl["total"].backward()
     torch.cuda.synchronize()
     return {k: float(v.detach()) for k, v in bl.items()}, model.flat_grads.detach().cpu().clone(), \
@@ -112,7 +114,7 @@ def _rccl_worker(port, q):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
-        cfg, sd, data, eps = _setup()
+        cfg, sd, data, eps = _setup(adv=False)  # (the faked world size has no second rank to gather the shuffled column from)
         out = {}
         for mode in ("plain", "ddp"):
             model, dis = build_model(cfg, sd)
@@ -144,6 +146,6 @@ def test_rccl_schedule_single_rank():
     g0, g1 = torch.from_numpy(g0), torch.from_numpy(g1)
     # the faked world size halves every loss term and hence (local BatchNorm statistics) every gradient
     for k, v in l0.items():
-        if not k.endswith("_gr"):  # recursive normalisation (losses.py:279-284): not linear in 1/B; scale 0 here
+        if not k.endswith(("_gr", "_an")):  # recursive normalisation (losses.py:279-284): not linear in 1/B; scale 0 here
             assert abs(2 * l1[k] - v) <= 1e-5 * abs(v), (k, l1[k], v)
     assert float((2 * g1 - g0).abs().max()) <= 1e-4 * float(g0.abs().max())

@@ -457,8 +457,17 @@ def test_split_gather_kernels(ops, case, code, pieces):
         raise
     assert relerr(from_nlc(yd, B, cv.l_out, Cout), y.detach()) < tol * math.sqrt(Cin * k) + tol
     assert float(yd[:, Cout:].abs().max() if cv.c_out_p > Cout else 0) == 0.0
-    cv.fwd(to_nlc(x.detach()), wd, bd, yd, accumulate=True)
+    # BatchNorm statistics from the epilogue (svae_conv_fwd_split_stats): per-tile (sum, sum of squares) of the values the launch
+    # WRITES (with accumulate: previous content included), summed over the tiles == column sums of the output
+    nt = cv.stats_tiles()
+    assert nt > 0
+    part = torch.full((nt, 2, cv.c_out_p), float("nan"), device="cuda")
+    cv.fwd(to_nlc(x.detach()), wd, bd, yd, accumulate=True, stats=part)
     assert relerr(from_nlc(yd, B, cv.l_out, Cout), 2 * y.detach()) < tol * math.sqrt(Cin * k) + tol
+    y2 = yd.double().cpu()
+    sums = part.double().cpu().sum(0)
+    assert not torch.isnan(part).any()
+    assert relerr(sums[0], y2.sum(0)) < 1e-5 * math.sqrt(y2.shape[0]) and relerr(sums[1], (y2 * y2).sum(0)) < 1e-5
     dxd = torch.full((B * L, cv.c_in_p), float("nan"), device="cuda")
     cv.dgrad(to_nlc(dy), wd, dxd)
     assert relerr(from_nlc(dxd, B, L, Cin), x.grad) < tol * math.sqrt(Cout * k) + tol
@@ -532,3 +541,132 @@ def test_split_weights_batched_matches_single(ops):
         assert cv._split_epoch == ops.WEIGHT_EPOCH
         n = ref.numel() - 64
         assert torch.equal(cv._wsplit[:n], ref[:n])
+
+
+# ------------------------------------------------------------------ fused MLP ensembles (csrc/ensemble.hip)
+class _StubLin:
+    """The attributes FusedEnsembleRunner reads from a LinearP: TIO weight [1][in_p][out_p], bias [out_p], their grads."""
+
+    def __init__(self, inf, outf, g, trainable=True):
+        p16 = lambda n: (n + 15) // 16 * 16
+        self.in_f, self.out_f, self.in_lib, self.out_lib = inf, outf, p16(inf), p16(outf)
+        self.w64 = torch.randn(inf, outf, generator=g, dtype=torch.float64) / math.sqrt(inf)
+        self.b64 = torch.randn(outf, generator=g, dtype=torch.float64) * 0.5
+        w = torch.zeros(1, self.in_lib, self.out_lib)
+        w[0, :inf, :outf] = self.w64.float()
+        b = torch.zeros(self.out_lib)
+        b[:outf] = self.b64.float()
+        self.weight, self.bias = w.cuda(), b.cuda()
+        self.weight.grad = torch.full_like(self.weight, 7.0) if trainable else None  # stale values: the kernel must overwrite
+        self.bias.grad = torch.full_like(self.bias, 7.0) if trainable else None
+
+
+class _StubEns:
+    def __init__(self, ind, outd, g, trainable=True):
+        self.in_dim, self.out_dim = ind, outd
+        dims = [[ind, ind, ind, outd], [ind, ind, outd], [ind, ind, ind // 2, outd], [ind, 2 * ind, 2 * ind, outd]]
+        self.m = [[_StubLin(a, b, g, trainable) for a, b in zip(d, d[1:])] for d in dims]
+
+    def members(self):
+        return self.m
+
+
+@pytest.mark.parametrize("case", [(8, 3, 37, 1), (32, 2, 200, 1), (37, 2, 70, 2), (13, 2, 5, 2), (32, 4, 64, 1)])
+def test_fused_ensemble_fwd_bwd(ops, case, monkeypatch):
+    """MLPEnsemble (disentangle.py:583-632) forward, input gradient (with the reversal coefficient, both halves of the
+    adversarial net's doubled batch summed) and parameter gradients on the fused kernels vs fp64 torch autograd."""
+    from scrubvae_amd.model import disentangle as D
+    monkeypatch.setattr(D, "LinearP", _StubLin)  # the runner picks the Linear layers of a member by isinstance
+    ind, outd, B, halves = case
+    g = torch.Generator().manual_seed(sum(case))
+    z = ind if halves == 1 else ind - 5
+    ens = _StubEns(ind, outd, g, trainable=(halves == 1))
+    r = D.FusedEnsembleRunner(ens, B, "cuda", halves)
+    assert r.fits()
+    zp = (z + 15) // 16 * 16
+    mu = torch.zeros(B, zp, dtype=torch.float64)
+    mu[:, :z] = torch.randn(B, z, generator=g, dtype=torch.float64)
+    var = torch.randn(B, 5, generator=g, dtype=torch.float64)
+    perm = torch.randperm(B, generator=g)
+    mu_c = mu.float().cuda()
+    if halves == 1:
+        outs = r.forward(mu_c, z)
+        x64 = mu[:, :z].clone().requires_grad_(True)
+        xin = x64
+    else:
+        outs = r.forward(mu_c, z, src1=var.float().cuda().contiguous(), perm=perm.cuda(), shuf_col=3)
+        x64 = mu[:, :z].clone().requires_grad_(True)
+        v2 = var.clone()
+        v2[:, 3] = var[perm, 3]
+        xin = torch.cat([torch.cat([x64, x64], 0), torch.cat([var, v2], 0)], 1)
+    ws = [[(l.w64.clone().requires_grad_(True), l.b64.clone().requires_grad_(True)) for l in mem] for mem in ens.m]
+    ref_outs = []
+    for mem in ws:
+        h = xin
+        for i, (w, b) in enumerate(mem):
+            h = h @ w + b
+            if i < len(mem) - 1:
+                h = torch.relu(h)
+        ref_outs.append(h)
+    for o, ro in zip(outs, ref_outs):
+        assert relerr(o.cpu()[:, :outd], ro.detach()) < 1e-5
+        assert float(o[:, outd:].abs().max()) == 0.0  # padded output columns stay zero
+    d_outs = [torch.randn(B * halves, outd, generator=g, dtype=torch.float64) for _ in range(4)]
+    for t, d in zip(r.d_outs, d_outs):
+        t.zero_()
+        t[:, :outd] = d.float().cuda()
+    torch.autograd.backward(ref_outs, d_outs)
+    d_mu = torch.full((B, zp), 0.25).cuda()
+    raw = r.backward(d_mu, -0.7, param_grads=(halves == 1), accumulate=False, want_raw=True)
+    torch.cuda.synchronize()
+    assert relerr(d_mu.cpu()[:, :z] - 0.25, -0.7 * x64.grad) < 2e-5
+    assert zp == z or float((d_mu[:, z:] - 0.25).abs().max()) == 0.0
+    if halves == 1:
+        assert relerr(raw.cpu()[:, :z], x64.grad) < 2e-5
+        for mem, refm in zip(ens.m, ws):
+            for l, (w, b) in zip(mem, refm):
+                assert relerr(l.weight.grad.cpu()[0, : l.in_f, : l.out_f], w.grad) < 2e-5
+                assert relerr(l.bias.grad.cpu()[: l.out_f], b.grad) < 2e-5
+                assert float(l.weight.grad[0, l.in_f:, :].abs().max() if l.in_lib > l.in_f else 0.0) == 0.0
+        # accumulate: a second backward adds onto the first
+        g0 = ens.m[3][1].weight.grad.clone()
+        r.backward(None, 0.0, param_grads=True, accumulate=True)
+        assert relerr(ens.m[3][1].weight.grad.cpu(), 2 * g0.cpu()) < 1e-6
+    else:
+        assert all(l.weight.grad is None for mem in ens.m for l in mem)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_fused_ensemble_losses(ops, kind):
+    """svae_ens_loss: the four members' losses / seed gradients in one launch vs the per-member kernels' definitions
+    (losses.py:267-309): summed squared error, CrossEntropy(sum), CrossEntropy applied to the softmax output."""
+    g = torch.Generator().manual_seed(kind)
+    rows, C, ld = 300, (3 if kind == 0 else (4 if kind == 1 else 2)), 16
+    outs64 = [torch.randn(rows, C, generator=g, dtype=torch.float64) for _ in range(4)]
+    outs = []
+    for o in outs64:
+        t = torch.zeros(rows, ld)
+        t[:, :C] = o.float()
+        outs.append(t.cuda())
+    lw, gs = [0.5, 0.25, 2.0, 1.0], [0.1, 0.2, 0.3, 0.4]
+    tgt = torch.randn(rows, C, generator=g, dtype=torch.float64)
+    labels = torch.randint(0, C, (rows,), generator=g)
+    dp = [torch.zeros(rows, ld).cuda() for _ in range(4)]
+    nb = ops.rowloss_blocks(rows)
+    part = torch.zeros(4 * nb).cuda()
+    ops.ens_loss(kind, outs, dp, lw, gs, tgt.float().cuda().contiguous() if kind == 0 else None, C,
+                 labels.int().cuda() if kind == 1 else None, rows, C, ld, part)
+    total = 0.0
+    for m, o in enumerate(outs64):
+        x = o.clone().requires_grad_(True)
+        if kind == 0:
+            l = ((x - tgt) ** 2).sum()
+        elif kind == 1:
+            l = F.cross_entropy(x, labels, reduction="sum")
+        else:
+            y = F.one_hot((torch.arange(rows) >= rows // 2).long(), 2).double()
+            l = F.cross_entropy(torch.softmax(x, -1), y, reduction="sum")
+        l.backward()
+        total += lw[m] * float(l)
+        assert relerr(dp[m].cpu()[:, :C], gs[m] * x.grad) < 2e-5
+    assert abs(float(part.double().sum()) - total) <= 2e-5 * abs(total)

@@ -40,7 +40,8 @@ def to_dev(data):
 
 
 @pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "rotation_tiny", "fullL_ids_tiny", "tc_tiny", "vanilla_default_B4",
-                                  "w256_tiny", "w256_6blocks_tiny", "linear_gr_tiny", "tanh_tiny"])
+                                  "w256_tiny", "w256_6blocks_tiny", "linear_gr_tiny", "tanh_tiny", "vanilla_default_j23_B4",
+                                  "full_j23_tiny"])
 def test_step0_matches_reference_fixture(golden_dir, name):
     from scrubvae_amd.train.losses import get_batch_loss
     fx, cfg, loss_scale, opt, sd, data = load_fixture(golden_dir, name)
@@ -119,7 +120,7 @@ def test_grads_vs_fp64_truth(golden_dir, name):
     assert worst_hip < 12 * worst_cpu + 1e-3, (worst_hip, worst_cpu)
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "linear_gr_tiny"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "linear_gr_tiny", "full_j23_tiny"])
 def test_three_steps_and_eval(golden_dir, name):
     """trainer-style loop (fused AdamW) for 3 steps, then eval-mode forward; same gates as the
     oracle's own multi-step test (Adam amplifies fp32 noise)."""
@@ -151,6 +152,10 @@ def test_three_steps_and_eval(golden_dir, name):
             assert rel(new_sd[k[9:]].cpu(), fx[k]) < 5e-3, k
         if k.startswith("final_sd/") and k.endswith("num_batches_tracked"):
             assert int(new_sd[k[9:]]) == int(fx[k])
+        if k.startswith("final_sd/disentangle.adversarial_net."):
+            # frozen discriminator (requires_grad=False, disentangle.py:670-671): torch's AdamW skips it, so no weight decay
+            # either -- bit-unchanged after the three steps, in the reference and here
+            assert torch.equal(new_sd[k[9:]].cpu(), torch.from_numpy(fx[k])) and torch.equal(sd[k[9:]], torch.from_numpy(fx[k])), k
     model.eval()
     with torch.no_grad():
         data_o = model(d)
@@ -296,8 +301,18 @@ def test_graphed_step_matches_eager():
         losses = [float(step()["total"]) for _ in range(3)]
         assert o.step_count == 6
         runs[capture] = (losses, m.flat_params.clone())
+        # replays queued WITHOUT a host sync in between (the host runs far ahead of the GPU), with a learning-rate change
+        # on the way: the step counter and bias corrections live on the device, the lr write is stream-ordered
+        for i in range(12):
+            if i == 6:
+                o.param_groups[0]["lr"] = 3e-4
+            step()
+        assert o.step_count == 18
+        torch.cuda.synchronize()
+        runs[capture] += (m.flat_params.clone(), float(o.hyper[3]))
     assert runs[True][0] == runs[False][0]
     assert torch.equal(runs[True][1], runs[False][1])
+    assert torch.equal(runs[True][2], runs[False][2]) and runs[True][3] == runs[False][3] == 18.0
     # reference-style loop
     m1, dis = build_model(cfg, sd)
     o1 = FusedAdam(m1, lr=1e-3, weight_decay=0.01, decoupled=True)
@@ -310,6 +325,29 @@ def test_graphed_step_matches_eager():
     # not bitwise: the captured step feeds Adam's bias-correction scalars from device floats, the loop computes them on
     # the host in double; six steps at lr 1e-3 amplify that last-bit difference to ~1e-4 relative in the loss
     assert abs(float(bl["total"].detach()) - runs[True][0][-1]) <= 1e-3 * abs(runs[True][0][-1])
+
+
+def test_clip_grad_norm_scales_like_torch():
+    """clip_grad_norm_ (trainer.py:164) with a max_norm that bites: gradients scaled by max_norm / (norm + 1e-6) as torch does;
+    with the reference's 1e6 they are left bit-unchanged."""
+    from scrubvae_amd.train.losses import get_batch_loss
+    from scrubvae_amd.train.trainer import clip_grad_norm_
+    cfg = O.OracleConfig(n_keypts=18, window=64, z_dim=8, kernel=5, channel=(16, 16, 16, 32, 32), diag=True, arena_size=ARENA)
+    sd = O.init_state_dict(cfg, seed=5)
+    data = to_dev(O.synth_batch(cfg, 8, seed=5))
+    m, dis = build_model(cfg, sd)
+    m.train()
+    bl = get_batch_loss(m, data, m(data), {"jpe": 1.0, "root": 1.0, "prior": 0.3}, dis)
+    bl["total"].backward()
+    g0 = m.flat_grads.clone()
+    n1 = clip_grad_norm_(m, 1e6)
+    assert torch.equal(m.flat_grads, g0)
+    p = torch.nn.Parameter(torch.zeros_like(g0))
+    p.grad = g0.clone()
+    n_t = torch.nn.utils.clip_grad_norm_([p], 0.5 * float(n1))
+    n2 = clip_grad_norm_(m, 0.5 * float(n1))
+    assert abs(float(n2) - float(n_t)) <= 1e-5 * float(n_t)
+    assert rel(m.flat_grads.cpu(), p.grad.cpu()) < 1e-6
 
 
 # ------------------------------------------------------------------ eval forward (SURVEY 8f N2)
@@ -422,7 +460,8 @@ def bf16x6_everywhere(request):
     ops.SPLIT_MIN_FLOPS = keep[1]
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "fullL_ids_tiny", "vanilla_default_B4", "w256_6blocks_tiny", "tanh_tiny"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "fullL_ids_tiny", "vanilla_default_B4", "w256_6blocks_tiny", "tanh_tiny",
+                                  "vanilla_default_j23_B4", "full_j23_tiny"])
 def test_step0_matches_reference_fixture_bf16x6(golden_dir, name, bf16x6_everywhere):
     """The reference fixtures at the SAME fp32 tolerances with the contractions on the bf16 matrix cores
     (bench.py's default precision): the 3-piece split is fp32-accurate, not a reduced-precision mode."""
@@ -645,11 +684,15 @@ def test_odd_shapes_vs_oracle(name, precision):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 5])
-def test_full_scvae_odd_batch_vs_oracle(B):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("B", [1, 5, 70])
+def test_full_scvae_odd_batch_vs_oracle(B, fused, monkeypatch):
     """configs[2]'s heads (conditional + gradient reversal incl. the ids classifier + adversarial net) at batch sizes the
-    fixtures do not have, against the oracle with the shuffle permutation injected."""
+    fixtures do not have (one sample, a ragged tile, more than one 64-row tile), against the oracle with the shuffle
+    permutation injected -- on the fused ensemble kernels and on the Linear-by-Linear GEMM path wide ensembles take."""
+    from scrubvae_amd import ops
     from scrubvae_amd.train.losses import get_batch_loss
+    monkeypatch.setattr(ops, "FUSED_ENSEMBLE", fused)
     feats = ["avg_speed_3d", "heading", "ids"]
     cfg = O.OracleConfig(n_keypts=18, window=64, z_dim=8, kernel=5, channel=(8, 8, 16, 16, 32), diag=True, arena_size=ARENA,
                          method={"conditional": feats, "grad_reversal": feats, "adversarial_net": ["heading"]}, features=feats,
@@ -665,6 +708,7 @@ def test_full_scvae_odd_batch_vs_oracle(B):
     d = to_dev(data)
     d["eps"] = eps.cuda()
     data_o = model(d)
+    assert all(r.fused == fused for r in model._runners.values())
     bl = get_batch_loss(model, d, data_o, ls, dis, adv_perm={"heading": perm})
     bl["total"].backward()
     for kk in bl_o:

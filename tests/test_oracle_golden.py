@@ -38,6 +38,15 @@ SCENARIOS = {
                        {"jpe": 1.0, "root": 1.0, "prior": 0.5, "ids_gr": 1.0}, "adam"),
     "vanilla_default_B4": (O.OracleConfig(n_keypts=18, window=64, z_dim=32, kernel=5, diag=True, arena_size=ARENA),
                            {"jpe": 1.0, "root": 1.0, "prior": 1.0}, "adamw"),
+    # BASELINE's 23-joint synthetic skeleton run through the REAL reference (make_fixtures.py --j23-only): default widths and
+    # the full SC-VAE head set at small widths
+    "vanilla_default_j23_B4": (O.OracleConfig(n_keypts=23, window=64, z_dim=32, kernel=5, diag=True, arena_size=ARENA,
+                                              kinematic_tree=O.skeleton_tree(23)),
+                               {"jpe": 1.0, "root": 1.0, "prior": 1.0}, "adamw"),
+    "full_j23_tiny": (O.OracleConfig(n_keypts=23, window=64, z_dim=8, kernel=5, channel=(8, 8, 16, 16, 32), diag=True, arena_size=ARENA,
+                                     kinematic_tree=O.skeleton_tree(23), method=FULL_METHODS, features=["avg_speed_3d", "heading"],
+                                     discrete_classes={"ids": torch.arange(4)}),
+                      {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_gr": 1.0, "heading_gr": 2.0, "heading_an": 0.5}, "adamw"),
     "linear_gr_tiny": (O.OracleConfig(diag=True, method={"linear": ["avg_speed_3d", "heading"], "grad_reversal": ["avg_speed_3d", "heading"]},
                                       features=["avg_speed_3d", "heading"], **TINY),
                        {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_lin": 0.6, "heading_lin": 1.5,
@@ -104,7 +113,7 @@ def test_oracle_step0_matches_reference(golden_dir, name):
     assert rel(gn, fx["s0/grad_norm"]) < (1e-2 if "rotation" in loss_scale else 1e-3)
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "linear_gr_tiny"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "linear_gr_tiny", "full_j23_tiny"])
 def test_oracle_multistep_and_eval(golden_dir, name):
     """3 optimizer steps then an eval-mode forward.  Adam amplifies fp32 noise (sign-like
     first step), the reference run at 1 vs 8 threads diverges ~1e-5/step: gate 2e-3."""
