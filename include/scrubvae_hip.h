@@ -119,6 +119,22 @@ int svae_conv_fwd_split_stats(const svae_conv_desc* d, const float* x, const voi
                               float* y, int accumulate, int pieces, float* bn_part, void* stream);
 int svae_conv_dgrad_split(const svae_conv_desc* d, const float* dy, const void* wsplit, float* dx,
                           int accumulate, int pieces, void* stream);
+/* The same launch when dx is the gradient with respect to the OUTPUT of a BatchNorm1d + PReLU / Tanh stage (the `add` / `residual.1-2`
+ * pairs of residual.py:88-89,112-113,146-147,173-174) whose saved input is f->x ([rows][ld_in], the layout of dx): the first pass of that
+ * stage's backward -- (sum du, sum du * xhat) per channel and the PReLU slope's partial, what svae_affine_prelu_bwd_partial computes
+ * from a re-read of dx and x -- comes out of the epilogue: part[tile][2][c_in], dalpha_part[tile * col_blocks + col_block], with
+ * svae_conv_dgrad_stats_tiles(d, &col_blocks) row tiles.  scale / shift (and mean / rstd) NULL: bare activation; alpha NULL: tanh.
+ * With accumulate the sums are those of the accumulated value (the launch that writes dx last carries them). */
+typedef struct {
+  const float* x;
+  const float* scale; const float* shift; const float* mean; const float* rstd;
+  const float* alpha;
+  float* part;
+  float* dalpha_part;   /* may be NULL (tanh) */
+} svae_bn_bwd_fuse;
+int svae_conv_dgrad_stats_tiles(const svae_conv_desc* d, int* col_blocks);
+int svae_conv_dgrad_split_bn(const svae_conv_desc* d, const float* dy, const void* wsplit, float* dx,
+                             int accumulate, int pieces, const svae_bn_bwd_fuse* f, void* stream);
 int svae_conv_wgrad_split(const svae_conv_desc* d, const float* x, const float* dy, float* dw,
                           float* db, void* ws, size_t ws_bytes, int accumulate, int pieces, void* stream);
 /* introspection: tile, kernel variant and (halo variant) image rows of the split fwd (0) / dgrad (1) launch */
@@ -176,15 +192,15 @@ int svae_affine_prelu_bwd_partial(const float* dy, const float* x, const float* 
                                   void* stream);
 /* pass 2: dx = gamma*rstd*(du - s0/count - xhat*s1/count)  (train-mode BN backward);
  * with sums == NULL: dx = du*scale (eval BN / bare PReLU: scale may be NULL => 1).
- * Also (+)= dgamma, dbeta from sums and dalpha from dalpha_part when those pointers are
- * given (done by block 0 only). */
+ * Also (+)= dgamma, dbeta from sums and dalpha from the n_parts entries of dalpha_part when those
+ * pointers are given. */
 int svae_affine_prelu_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift,
                                 const float* mean, const float* rstd, const float* gamma,
                                 const float* alpha, const float* sums, double count,
                                 float* dx, long long rows, int C, int ld,
                                 float* dgamma, float* dbeta, float* dalpha,
-                                const float* dalpha_part, int n_chunks, int accumulate_param_grads,
-                                void* stream);
+                                const float* dalpha_part, int n_parts, int accumulate_param_grads,
+                                void* stream);   /* n_parts = entries of dalpha_part */
 
 /* nn.Upsample(scale_factor=2, mode="linear", align_corners=False) (residual.py:160) */
 int svae_upsample2_fwd(const float* x, float* y, int batch, int l_in, int C, int ld, void* stream);

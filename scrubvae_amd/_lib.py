@@ -53,6 +53,10 @@ class EnsDesc(C.Structure):
                 ("shuf_vals", C.c_void_p)]
 
 
+class BnBwdFuse(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "scale", "shift", "mean", "rstd", "alpha", "part", "dalpha_part")]
+
+
 class Tree(C.Structure):
     _fields_ = [("n_joints", C.c_int), ("n_chains", C.c_int),
                 ("chain_len", C.c_int * MAX_CHAINS),
@@ -96,6 +100,8 @@ SIGNATURES = {
     "svae_conv_fwd_stats_tiles": (I, [DP]),
     "svae_conv_fwd_split_stats": (I, [DP, P, P, P, P, I, I, P, P]),
     "svae_conv_dgrad_split": (I, [DP, P, P, P, I, I, P]),
+    "svae_conv_dgrad_stats_tiles": (I, [DP, C.POINTER(I)]),
+    "svae_conv_dgrad_split_bn": (I, [DP, P, P, P, I, I, C.POINTER(BnBwdFuse), P]),
     "svae_conv_wgrad_split": (I, [DP, P, P, P, P, P, SZ, I, I, P]),
     "svae_conv_split_tile": (I, [DP, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I)]),
     "svae_pack_input": (I, [P, P, C.POINTER(F), P, LL, I, I, P]),

@@ -753,7 +753,7 @@ extern "C" int svae_affine_prelu_bwd_partial(const float* dy, const float* x, co
 extern "C" int svae_affine_prelu_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift,
                                            const float* mean, const float* rstd, const float* gamma, const float* alpha,
                                            const float* sums, double count, float* dx, long long rows, int C, int ld,
-                                           float* dgamma, float* dbeta, float* dalpha, const float* dalpha_part, int n_chunks,
+                                           float* dgamma, float* dbeta, float* dalpha, const float* dalpha_part, int n_parts,
                                            int accumulate_param_grads, void* stream) {
   SVAE_REQUIRE(dy && x && dx && rows > 0, SVAE_ERR_ARG, "affine_prelu_bwd_apply: null pointer");
   SVAE_REQUIRE(!sums || (mean && rstd && gamma && count > 0), SVAE_ERR_ARG, "affine_prelu_bwd_apply: BN tensors missing");
@@ -761,7 +761,6 @@ extern "C" int svae_affine_prelu_bwd_apply(const float* dy, const float* x, cons
                      mean, rstd, gamma, alpha, sums, sums ? (float)(1.0 / count) : 0.f, dx, rows, C, ld);
   if (int e = check_launch("affine_prelu_bwd_apply")) return e;
   if (dgamma || dbeta || dalpha) {
-    const int n_parts = n_chunks * ((C + 63) / 64);
     hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), sums, C, dgamma, dbeta, dalpha,
                        dalpha_part, n_parts, accumulate_param_grads);
     return check_launch("bn_param_grads");

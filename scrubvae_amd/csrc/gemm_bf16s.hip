@@ -82,6 +82,9 @@ __device__ __forceinline__ f32x16 mfma_split(const uint4 (&a)[P], const uint4 (&
   return acc;
 }
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+
 constexpr int SBK = 32;  // K depth of one LDS stage: a 128-byte line of every gathered fp32 row
 
 struct SplitGatherArgs {
@@ -101,6 +104,10 @@ template <int MT, int NT, int WM, int WN, int WR, int BN>
 __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)[MT][NT], const long long* rowoff, int n0, int wr, int wc,
                                               int lr, int h, float* red, int tid, int nth) {
   float cs[NT], cq[NT];
+  float da = 0.f;
+  const bool bwd = g.bn_x != nullptr;        // uniform
+  const bool th = g.bn_alpha == nullptr;     // tanh instead of PReLU
+  const float slope = (bwd && !th) ? g.bn_alpha[0] : 0.f;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = n0 + wc * WN + nt * 32 + lr;
@@ -108,6 +115,11 @@ __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)
     cq[nt] = 0.f;
     if (col >= g.N) continue;
     const float bv = g.bias ? g.bias[col] : 0.f;
+    float sc = 1.f, sh = 0.f, mu = 0.f, rs = 0.f;
+    if (bwd) {
+      if (g.bn_scale) { sc = g.bn_scale[col]; sh = g.bn_shift[col]; }
+      if (g.bn_mean) { mu = g.bn_mean[col]; rs = g.bn_rstd[col]; }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -119,8 +131,18 @@ __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)
           float v = acc[mt][nt][r] + bv;
           if (g.accumulate) v += *dst;
           *dst = v;
-          cs[nt] += v;
-          cq[nt] += v * v;
+          if (bwd) {
+            const float x = g.bn_x[off + col];
+            const float u = x * sc + sh;
+            float du;
+            if (th) { const float t = tanhf(u); du = v * (1.f - t * t); }
+            else { du = u > 0.f ? v : slope * v; if (!(u > 0.f)) da += v * u; }
+            cs[nt] += du;
+            cq[nt] += du * (x - mu) * rs;
+          } else {
+            cs[nt] += v;
+            cq[nt] += v * v;
+          }
         }
       }
     }
@@ -140,6 +162,11 @@ __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)
       red[(1 * WR + wr) * BN + c] = cq[nt];
     }
   }
+  float* dred = red + 2 * WR * BN;  // one slot per wave for the slope partial
+  if (bwd && g.bn_dalpha) {
+    da = wave_sum(da);
+    if ((tid & 63) == 0) dred[tid >> 6] = da;
+  }
   __syncthreads();
   for (int i = tid; i < 2 * BN; i += nth) {
     const int k = i / BN, c = i - k * BN;
@@ -147,6 +174,11 @@ __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)
 #pragma unroll
     for (int w = 0; w < WR; ++w) t += red[(k * WR + w) * BN + c];
     if (n0 + c < g.N) g.stats[((long long)blockIdx.x * 2 + k) * g.N + n0 + c] = t;
+  }
+  if (bwd && g.bn_dalpha && tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < nth / 64; ++w) t += dred[w];
+    g.bn_dalpha[(long long)blockIdx.x * gridDim.y + blockIdx.y] = t;
   }
 }
 
@@ -832,6 +864,317 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
   tile_epilogue<MT, NT, WM, WN, WR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), tid, NTH);
 }
 
+// ------------------------------------------- halo-image gather GEMM, wave-specialised (fwd / dgrad)
+// In gather_halo_bf16s_kernel every wave stages AND computes: hipcc sinks the weight-tile loads of the next stage to the end of
+// the current one and waits for them (vmcnt(0)) at the top of the next, so every stage exposes one L2 round trip plus the LDS
+// writes on all eight waves at once -- the matrix cores idle for ~2,000 of a stage's ~5,500 cycles (rocprof: 0.43-0.55 busy).
+// Here the roles are split: WR x WC CONSUMER waves issue nothing but operand fetches (ds_read_b128) and MFMAs; two PRODUCER waves
+// (dispatched last: they land on SIMDs 0 and 2 beside two consumers each) feed them:
+//   * the pre-split weight tile of the next stage goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip,
+//     no ds_write; the XOR swizzle of the image is applied to the per-lane SOURCE address), double-buffered;
+//   * the activation image of the NEXT 32-channel block is loaded a block ahead into producer registers, split into bf16
+//     pieces and written to the second image buffer while the consumers work on the current one (two image buffers).
+// One barrier per stage, shared by both roles; the consumers never wait for global memory.
+__device__ __attribute__((aligned(16))) unsigned short halo_zero_chunk[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // source of weight rows past N
+
+// DBG (timing experiments only, wrong results; python scrubvae_amd/build.py --ablation): 1 = producers issue no global loads / DMA,
+// 2 = consumers issue no LDS operand fetches, 4 = consumers issue no MFMAs, 8 = no per-stage barrier in the consumers' loop
+// PIPE: pin the fetch / multiply blocks of the consumers' software pipeline with sched_barrier (hipcc otherwise sinks every operand
+// fetch down to its first use and the ds_read latency is exposed again).  Costs registers: both k-steps' fragments stay live, which
+// fits the 168 VGPRs of a 10-wave workgroup with 2 pieces (64 x 64 wave tile) or with 3 pieces on a 64 x 32 wave tile (BN = 64).
+// NB: weight-tile buffers.  2: the tile of stage s + 1 is requested in interval s and must have landed by its end -- with 2 pieces
+// an interval's matrix work (~0.7 us) is shorter than the DMA's L2 round trip (~1 us), the producers become the critical path.
+// 3: the tile of stage s + 2 is requested in interval s; the producers wait with a COUNTED vmcnt that leaves this interval's
+// requests in flight (bare s_barrier + explicit waits: __syncthreads() would drain them all).
+template <int BM, int BN, int P, int WR, int WC, int RMAX, int DBG = 0, bool PIPE = false, int NB = 2>
+__global__ __launch_bounds__(64 * (WR * WC + 2)) void gather_halo_ws_bf16s_kernel(const SplitGatherArgs sa) {
+  const GatherArgs& g = sa.g;
+  constexpr int NCT = 64 * WR * WC;   // consumer threads
+  constexpr int NPT = 128;            // producer threads (2 waves)
+  constexpr int WM = BM / WR, MT = WM / 32, WN = BN / WC, NT = WN / 32;
+  static_assert(MT >= 1 && NT >= 1 && WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+  static_assert(BM <= NCT, "rowoff is filled by the consumer threads");
+  constexpr int ROWB = SBK * 2;
+  constexpr int A_PIECE = RMAX * ROWB, B_PIECE = BN * ROWB;
+  constexpr int A_IMG = P * A_PIECE, B_STAGE = P * B_PIECE;
+  static_assert(2 * A_IMG + NB * B_STAGE + BM * 8 <= 160 * 1024, "LDS budget");
+  static_assert(NB == 2 || NB == 3, "2 or 3 weight buffers");
+  constexpr int RPP = NPT / 8;                     // image rows per producer pass (8 lanes x float4 per row)
+  constexpr int APASS = (RMAX + RPP - 1) / RPP;
+  constexpr int B_INSTR = B_STAGE / 1024;          // 1-KiB DMA wave-instructions per weight stage
+  static_assert(B_STAGE % 2048 == 0, "weight stage must split evenly over the two producer waves");
+  constexpr int BPW = B_INSTR / 2;                 // per producer wave
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_IMG + NB * B_STAGE];
+  __shared__ long long rowoff[BM];
+  unsigned char* const bbase = smem + 2 * A_IMG;
+
+  const int tid = threadIdx.x;
+  int bx = blockIdx.x, phase = 0;
+  if (bx >= g.blocks_m[0]) { phase = 1; bx -= g.blocks_m[0]; }
+  const long long m0 = (long long)bx * BM;
+  const int n0 = blockIdx.y * BN;
+  const long long Mp = g.M[phase];
+  const int nj = g.nj[phase];
+  const int ntaps = g.ntaps[phase];
+  // tap tables in closed form (gemm_common.h: plan_is_affine, checked on the host): no scalar loads inside the stage loop
+  const int tb0 = g.base0[phase], tbs = g.bstep[phase], tw0 = g.w0[phase], tws = g.wstep[phase];
+  const int tbl = tb0 + (ntaps - 1) * tbs;
+  const int bmin = tb0 < tbl ? tb0 : tbl, bmax = tb0 < tbl ? tbl : tb0;
+  const long long b0 = m0 / nj;
+  const long long amin = b0 * g.Lin + (long long)(m0 - b0 * nj) * g.sj;
+  const long long ml = (m0 + BM < Mp ? m0 + BM : Mp) - 1;
+  const long long bl = ml / nj;
+  const long long amax = bl * g.Lin + (long long)(ml - bl * nj) * g.sj;
+  const int R = (int)(amax - amin) + bmax - bmin + 1;  // <= RMAX (checked on the host)
+  const long long gbase = amin + bmin;
+  const long long kb_stride = (long long)g.N * SBK;
+  const long long tap_stride = kb_stride * sa.KB;
+  const int ns = ntaps * sa.KB;
+
+  if (tid >= NCT) {
+    // ================================================================== producer waves
+    const int ptid = tid - NCT;
+    const int pw = __builtin_amdgcn_readfirstlane(ptid >> 6), lane = ptid & 63;
+    // weight DMA: wave-instruction i of this wave fills LDS bytes [(2 i + pw) KiB, +1 KiB) of the stage: chunk q = 64 (2 i + pw) + lane
+    long long b_src[BPW];
+    bool b_ok[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+      const int q = 64 * (2 * i + pw) + lane;
+      const int piece = q / (BN * 4), rem = q - piece * (BN * 4);
+      const int row = rem >> 2, slot = rem & 3;
+      b_ok[i] = n0 + row < g.N;
+      b_src[i] = (long long)piece * sa.w_piece_stride + (long long)(n0 + row) * SBK + ((slot ^ swz(row)) << 3);
+    }
+    auto dma_b = [&](int tap, int kb, int buf) {
+      const unsigned short* wt = sa.Wp + (long long)(tw0 + tap * tws) * tap_stride + (long long)kb * kb_stride;
+#pragma unroll
+      for (int i = 0; i < BPW; ++i) {
+        const unsigned short* src = b_ok[i] ? wt + b_src[i] : halo_zero_chunk;
+        if constexpr (!(DBG & 1))
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(bbase + buf * B_STAGE + (2 * i + pw) * 1024), 16, 0, 0);
+      }
+    };
+    // activation image: 8 lanes per row, RPP rows per pass
+    const int akq = ptid & 7;
+    long long a_goff[APASS];
+    bool a_row_ok[APASS];
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int r = (ptid >> 3) + RPP * i;
+      const long long grow = gbase + r;
+      a_row_ok[i] = r < R && grow >= 0 && grow < sa.rowsA;
+      a_goff[i] = (a_row_ok[i] ? grow : 0) * (long long)g.ldA;
+    }
+    float4 ra[APASS];
+    bool ra_kq;
+    auto load_a = [&](int kb) {
+      const int c0 = kb * SBK;
+      ra_kq = c0 + akq * 4 < g.Kc;
+      const int cq = ra_kq ? c0 + akq * 4 : 0;
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        if constexpr (DBG & 1) ra[i] = make_float4(1.f + i, 2.f, 3.f + cq, 4.f);
+        else ra[i] = *reinterpret_cast<const float4*>(g.A + a_goff[i] + cq);
+      }
+    };
+    auto store_a = [&](int buf) {
+      unsigned char* img = smem + buf * A_IMG;
+#pragma unroll
+      for (int i = 0; i < APASS; ++i) {
+        const int r = (ptid >> 3) + RPP * i;
+        uint2 pc[P];
+        split4<P>((a_row_ok[i] && ra_kq) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f), pc);
+        const int off = r * ROWB + (((akq >> 1) ^ swz(r)) << 4) + ((akq & 1) << 3);
+        if ((i + 1) * RPP <= RMAX || r < RMAX) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(img + p * A_PIECE + off) = pc[p];
+        }
+      }
+    };
+    if constexpr (NB == 2) {
+      if (ns > 0) {
+        load_a(0);
+        dma_b(0, 0, 0);
+        store_a(0);
+        load_a(sa.KB > 1 ? 1 : 0);
+      }
+      __syncthreads();  // (hipcc waits for the DMA in flight here)
+      int tap = 0, kb = 0;
+      for (int s = 0; s < ns; ++s) {
+        // stage s + 1's weight tile
+        int ntap = tap + 1, nkb = kb;
+        if (ntap == ntaps) { ntap = 0; ++nkb; }
+        if (s + 1 < ns) dma_b(ntap, nkb, (s + 1) & 1);
+        if (tap == 0 && kb + 1 < sa.KB) {  // the next channel block's image, into the buffer the consumers left one block ago
+          store_a((kb + 1) & 1);
+          load_a(kb + 2 < sa.KB ? kb + 2 : kb + 1);
+        }
+        __syncthreads();
+        tap = ntap;
+        kb = nkb;
+      }
+    } else {
+      // (tap, block) of stages s + 1 and s + 2
+      int t1 = 0, k1 = 0;
+      auto advance = [&](int& t, int& k) { if (++t == ntaps) { t = 0; ++k; } };
+      if (ns > 0) {
+        load_a(0);
+        dma_b(0, 0, 0);
+        advance(t1, k1);
+        if (ns > 1) dma_b(t1, k1, 1);
+        store_a(0);
+        load_a(sa.KB > 1 ? 1 : 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      int tap = 0, kb = 0;
+      int t2 = t1, k2 = k1;
+      advance(t2, k2);
+      for (int s = 0; s < ns; ++s) {
+        const bool do_dma = s + 2 < ns;
+        const bool do_img = tap == 0 && kb + 1 < sa.KB;
+        if (do_img) store_a((kb + 1) & 1);  // (its loads were requested a whole channel block ago)
+        if (do_dma) dma_b(t2, k2, (s + 2) % 3);
+        if (do_img) load_a(kb + 2 < sa.KB ? kb + 2 : kb + 1);
+        // everything older than THIS interval's requests has landed: stage s + 1's weight tile (requested one interval ago) is complete
+        if (do_dma && do_img) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BPW + APASS) : "memory");
+        else if (do_dma) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BPW) : "memory");
+        else if (do_img) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(APASS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        advance(tap, kb);
+        advance(t2, k2);
+      }
+    }
+    return;
+  }
+
+  // ==================================================================== consumer waves
+  if (tid < BM) {
+    const long long m = m0 + tid;
+    long long off = -1;
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      off = (b * g.Lout + (phase + g.n_phase * j)) * (long long)g.ldC;
+    }
+    rowoff[tid] = off;
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave / WC, wc = wave % WC;
+  const int lr = lane & 31, h = lane >> 5;
+  int ro[MT], jj[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const long long m = m0 + wr * WM + mt * 32 + lr;
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      ro[mt] = (int)(b * g.Lin + (long long)j * g.sj - amin) - bmin;
+      jj[mt] = j * g.sj;
+    } else {
+      ro[mt] = -bmin;
+      jj[mt] = -(1 << 28);
+    }
+  }
+  int b_addr[NT], b_sw[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int row = wc * WN + nt * 32 + lr;
+    b_addr[nt] = row * ROWB;
+    b_sw[nt] = swz(row);
+  }
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  __syncthreads();
+  {
+    uint4 av[2][MT][P], bv[2][NT][P];
+    int tap = 0, kb = 0;
+    // stage whose operands are being fetched: tap offset, validity masks, image / weight-stage base
+    int tb = 0;
+    const unsigned char* img = smem;
+    const unsigned char* bst = bbase;
+    auto begin_stage = [&](int s) {
+      tb = tb0 + tap * tbs;
+      img = smem + (kb & 1) * A_IMG;
+      bst = bbase + (NB == 2 ? (s & 1) : (s % 3)) * B_STAGE;
+      if (++tap == ntaps) { tap = 0; ++kb; }
+    };
+    // operand fragments of 16-deep k-step ks of the current stage (raw: the padding-row mask is applied by the consumer of the
+    // registers, so nothing in here waits for a load)
+    unsigned amask[2][MT];
+    auto fetch = [&](auto ks_c, int s) {
+      constexpr int ks = decltype(ks_c)::value;
+      const int ch = ks * 2 + h;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int arow = ro[mt] + tb;
+        amask[ks][mt] = (unsigned)(jj[mt] + tb) < (unsigned)g.Lin ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if constexpr (DBG & 2) av[ks][mt][p] = make_uint4(s + arow, ks, mt, p);
+          else av[ks][mt][p] = *reinterpret_cast<const uint4*>(img + p * A_PIECE + arow * ROWB + ((ch ^ swz(arow)) << 4));
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          if constexpr (DBG & 2) bv[ks][nt][p] = make_uint4(s, ks + b_addr[nt], nt, p);
+          else bv[ks][nt][p] = *reinterpret_cast<const uint4*>(bst + p * B_PIECE + b_addr[nt] + ((ch ^ b_sw[nt]) << 4));
+        }
+    };
+    auto mma = [&](auto ks_c) {
+      constexpr int ks = decltype(ks_c)::value;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const unsigned mask = amask[ks][mt];
+#pragma unroll
+        for (int p = 0; p < P; ++p) { av[ks][mt][p].x &= mask; av[ks][mt][p].y &= mask; av[ks][mt][p].z &= mask; av[ks][mt][p].w &= mask; }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (DBG & 4) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[mt][nt][p] += __builtin_bit_cast(float, av[ks][mt][p].x ^ bv[ks][nt][p].y);
+          } else {
+            acc[mt][nt] = mfma_split<P>(av[ks][mt], bv[ks][nt], acc[mt][nt]);
+          }
+        }
+    };
+    // Software pipeline over half stages: the operand fetches of one 16-deep k-step are issued in front of the MFMAs of the
+    // previous one, so every ds_read has a k-step's worth of matrix work (MT x NT x products MFMAs) to land behind:
+    //   interval s:  fetch k0(s) | mma k1(s-1) | fetch k1(s) | mma k0(s) | barrier
+    // Both fetches of stage s fall between barrier s-1 (which published its weight tile) and barrier s (after which the
+    // producers may overwrite it), the same hand-over protocol as a fetch-everything-then-multiply loop.
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    for (int s = 0; s < ns; ++s) {
+      begin_stage(s);
+      fetch(K0{}, s);
+      if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+      if (s > 0) mma(K1{});
+      if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+      fetch(K1{}, s);
+      if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+      mma(K0{});
+      if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+    }
+    if (ns > 0) mma(K1{});
+  }
+  tile_epilogue<MT, NT, WM, WN, WR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), tid, NCT);
+}
+
 // ---------------------------------------------------------------------------- weight split
 // w[tap][c_in][c_out] fp32 -> bf16 piece planes, pre-tiled in the order the GEMM stages them:
 //   plane(n, k) at [piece][tap][k/32][n][k%32], k zero-padded to a multiple of 32.
@@ -1122,7 +1465,7 @@ template <int BM, int BN, int NSTAGE, int WR, int WC>
 static int launch_wgrad_big(const WgradArgs& g, dim3 grid, hipStream_t st, int pieces) {
   if (pieces == 2) hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 2, NSTAGE, WR, WC>), grid, dim3(64 * WR * WC), 0, st, g);
   else if (pieces == 3 && NSTAGE == 1) hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 3, 1, WR, WC>), grid, dim3(64 * WR * WC), 0, st, g);
-  else { set_error("wgrad split: the 256-edge tiles are built for 2 pieces (3 pieces: single LDS buffer only)"); return SVAE_ERR_ARG; }
+  else { set_error("wgrad split: the 256-edge tiles are built for 2 pieces (3 pieces: single LDS buffer only)"); return SVAE_ERR_SHAPE; }
   return SVAE_OK;
 }
 
@@ -1142,7 +1485,7 @@ int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, in
   }
   SVAE_WG_BIG(256, 256, 2, 4) SVAE_WG_BIG(256, 128, 4, 2) SVAE_WG_BIG(128, 256, 2, 4)
 #undef SVAE_WG_BIG
-  else { set_error("wgrad split: tile %dx%d unsupported", bm, bn); return SVAE_ERR_ARG; }
+  else { set_error("wgrad split: tile %dx%d unsupported", bm, bn); return SVAE_ERR_SHAPE; }
   return check_launch("wgrad_gemm_bf16s");
 }
 
@@ -1202,8 +1545,8 @@ static int halo_rows(const GatherArgs& g, int bm) {
 
 template <int BN>
 static int launch_halo(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
-  if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_ARG; }
-  if (rows > 264) { set_error("split gather: halo image of %d rows does not fit", rows); return SVAE_ERR_ARG; }
+  if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
+  if (rows > 264) { set_error("split gather: halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
   if (pieces == 3) {
     if (rows <= 160) hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 3, 4, 2, 160>), grid, dim3(512), 0, st, sa);
     else hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 3, 4, 2, 264>), grid, dim3(512), 0, st, sa);
@@ -1218,8 +1561,8 @@ static int launch_halo(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int
 // the vector-memory path; pays once the problem has >= 2 x 256 such row tiles (batch >= 2048 for the deep layers)
 template <int BN>
 static int launch_halo256(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
-  if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_ARG; }
-  if (rows > 528 || (pieces == 3 && rows > 320 && BN > 64)) { set_error("split gather: 256-row halo image of %d rows does not fit", rows); return SVAE_ERR_ARG; }
+  if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
+  if (rows > 528 || (pieces == 3 && rows > 320 && BN > 64)) { set_error("split gather: 256-row halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
   if (pieces == 3) {
     if (rows <= 320) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 3, 4, 2, 320>), grid, dim3(512), 0, st, sa);
     else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 64, 3, 4, 2, 528>), grid, dim3(512), 0, st, sa);
@@ -1227,6 +1570,46 @@ static int launch_halo256(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, 
     if (rows <= 320) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 2, 4, 2, 320>), grid, dim3(512), 0, st, sa);
     else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 2, 4, 2, 528>), grid, dim3(512), 0, st, sa);
   }
+  return SVAE_OK;
+}
+
+// V = 10 / 11: the wave-specialised halo kernel (8 consumer + 2 producer waves) on 128- / 256-row tiles (row field of the code: 128).
+// Instantiated where two image buffers + two weight stages fit the 160 KiB of LDS.
+template <int BM, int BN>
+static int launch_halo_ws(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
+  const dim3 block(64 * 10);
+  if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernels are built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
+#define SVAE_HWS(P_, R_) hipLaunchKernelGGL((gather_halo_ws_bf16s_kernel<BM, BN, P_, 4, 2, R_>), grid, block, 0, st, sa)
+  if constexpr (BM == 128) {
+    if (rows <= 160) { if (pieces == 3) SVAE_HWS(3, 160); else SVAE_HWS(2, 160); }
+    else if (rows <= 264) { if (pieces == 3) SVAE_HWS(3, 264); else SVAE_HWS(2, 264); }
+    else { set_error("split gather: halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
+  } else {
+    if (rows <= 264) { if (pieces == 3) SVAE_HWS(3, 264); else SVAE_HWS(2, 264); }
+    else if (rows <= 320 && pieces == 2) SVAE_HWS(2, 320);
+    else { set_error("split gather: 256-row halo image of %d rows does not fit twice", rows); return SVAE_ERR_SHAPE; }
+  }
+#undef SVAE_HWS
+  return SVAE_OK;
+}
+
+// V = 12 / 13: the same kernel with three weight-tile buffers (the producers request two stages ahead): 2 pieces on BN = 128 or 64,
+// 3 pieces on BN = 64 (LDS)
+template <int BM, int BN>
+static int launch_halo_ws_pipe(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
+  const dim3 block(64 * 10);
+  if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernels are built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
+  if (pieces == 3 && BN != 64) { set_error("split gather: three weight buffers with 3 pieces exist for 64-column tiles only"); return SVAE_ERR_SHAPE; }
+#define SVAE_HWP(P_, R_) hipLaunchKernelGGL((gather_halo_ws_bf16s_kernel<BM, BN, P_, 4, 2, R_, 0, false, 3>), grid, block, 0, st, sa)
+  constexpr int R0 = BM == 128 ? 160 : 264;
+  if (rows <= R0) {
+    if (pieces == 2) SVAE_HWP(2, R0);
+    else if constexpr (BN == 64) SVAE_HWP(3, R0);
+  } else if (BM == 128 && rows <= 264) {
+    if (pieces == 2) SVAE_HWP(2, 264);
+    else if constexpr (BN == 64) SVAE_HWP(3, 264);
+  } else { set_error("split gather: halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
+#undef SVAE_HWP
   return SVAE_OK;
 }
 
@@ -1239,8 +1622,39 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
   Tile t;
   if (!decode_tile(code, t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
   const int v = t.dma;
+#ifdef SVAE_ABLATION_KERNELS
+  if (v >= 20 && v < 28 && (pieces == 3 || pieces == 2)) {  // timing experiments on the 256 x 128 wave-specialised halo kernel: V = 20 + DBG
+    for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + 255) / 256);
+    const int nb = g.blocks_m[0] + g.blocks_m[1];
+    if (nb == 0) return SVAE_OK;
+    dim3 gridw(nb, (g.N + 127) / 128), block(640);
+    if (halo_rows(g, 256) > 264) { set_error("ablation: image does not fit"); return SVAE_ERR_SHAPE; }
+#define SVAE_HD(D_) case D_: if (pieces == 3) hipLaunchKernelGGL((gather_halo_ws_bf16s_kernel<256, 128, 3, 4, 2, 264, D_>), gridw, block, 0, st, sa); \
+                             else hipLaunchKernelGGL((gather_halo_ws_bf16s_kernel<256, 128, 2, 4, 2, 264, D_, false, 3>), gridw, block, 0, st, sa); break;
+    switch (v - 20) { SVAE_HD(0) SVAE_HD(1) SVAE_HD(2) SVAE_HD(3) SVAE_HD(4) SVAE_HD(5) SVAE_HD(6) SVAE_HD(7) default: break; }
+#undef SVAE_HD
+    return check_launch("gather_halo_ws_bf16s<dbg>");
+  }
+#endif
+  if (v >= 10 && v <= 13) {
+    if (t.bm != 128) { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_SHAPE; }
+    const int bmr = (v == 11 || v == 13) ? 256 : 128;
+    for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + bmr - 1) / bmr);
+    const int nb = g.blocks_m[0] + g.blocks_m[1];
+    if (nb == 0) return SVAE_OK;
+    dim3 gridw(nb, (g.N + t.bn - 1) / t.bn);
+    const int rows = halo_rows(g, bmr);
+    if (!plan_is_affine(g)) { set_error("split gather: tap tables are not arithmetic progressions"); return SVAE_ERR_SHAPE; }
+    int e;
+    if (v == 10) e = t.bn == 128 ? launch_halo_ws<128, 128>(sa, gridw, st, pieces, rows) : launch_halo_ws<128, 64>(sa, gridw, st, pieces, rows);
+    else if (v == 11) e = t.bn == 128 ? launch_halo_ws<256, 128>(sa, gridw, st, pieces, rows) : launch_halo_ws<256, 64>(sa, gridw, st, pieces, rows);
+    else if (v == 12) e = t.bn == 128 ? launch_halo_ws_pipe<128, 128>(sa, gridw, st, pieces, rows) : launch_halo_ws_pipe<128, 64>(sa, gridw, st, pieces, rows);
+    else e = t.bn == 128 ? launch_halo_ws_pipe<256, 128>(sa, gridw, st, pieces, rows) : launch_halo_ws_pipe<256, 64>(sa, gridw, st, pieces, rows);
+    if (e) return e;
+    return check_launch("gather_halo_ws_bf16s");
+  }
   if (v == 9) {  // 256-row halo tiles, encoded with a 128 row field
-    if (t.bm != 128) { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_ARG; }
+    if (t.bm != 128) { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_SHAPE; }
     for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + 255) / 256);
     const int nb = g.blocks_m[0] + g.blocks_m[1];
     if (nb == 0) return SVAE_OK;
@@ -1273,7 +1687,7 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
     else if (v == 7) launch_split_ws<BM_, BN_, 2, 2, 3>(sa, grid, st, pieces);                \
     else if (v == 8 && BM_ == 128) { if (int e = launch_halo<BN_>(sa, grid, st, pieces, halo_rows(g, 128))) return e; } \
     SVAE_ABLATION_CASE(BM_, BN_)                                                           \
-    else { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_ARG; } \
+    else { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_SHAPE; } \
   }
   SVAE_SPLIT_CASE(128, 128) else SVAE_SPLIT_CASE(128, 64) else SVAE_SPLIT_CASE(64, 128) else SVAE_SPLIT_CASE(64, 64)
 #undef SVAE_SPLIT_CASE
@@ -1310,7 +1724,7 @@ extern "C" int svae_conv_fwd_stats_tiles(const svae_conv_desc* d) {
   build_plan(g, d, !d->transposed, d->l_out, d->l_in);
   Tile t;
   if (!decode_tile(d->tile[0], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
-  const int bm = t.dma == 9 ? 256 : t.bm;
+  const int bm = (t.dma == 9 || t.dma == 11 || t.dma == 13) ? 256 : t.bm;
   return (int)((g.M[0] + bm - 1) / bm + (g.M[1] + bm - 1) / bm);
 }
 
@@ -1341,8 +1755,27 @@ extern "C" int svae_conv_fwd_split_stats(const svae_conv_desc* d, const float* x
   return launch_split_gather(sa, (hipStream_t)stream, d->tile[0], pieces);
 }
 
+// row tiles / column blocks of the split data-gradient launch for the descriptor's current tile choice
+extern "C" int svae_conv_dgrad_stats_tiles(const svae_conv_desc* d, int* col_blocks) {
+  if (validate(d)) return 0;
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  g.N = d->c_in;
+  build_plan(g, d, d->transposed != 0, d->l_in, d->l_out);
+  Tile t;
+  if (!decode_tile(d->tile[1], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
+  const int bm = (t.dma == 9 || t.dma == 11 || t.dma == 13) ? 256 : t.bm;
+  if (col_blocks) *col_blocks = (g.N + t.bn - 1) / t.bn;
+  return (int)((g.M[0] + bm - 1) / bm + (g.M[1] + bm - 1) / bm);
+}
+
 extern "C" int svae_conv_dgrad_split(const svae_conv_desc* d, const float* dy, const void* wsplit, float* dx, int accumulate,
                                      int pieces, void* stream) {
+  return svae_conv_dgrad_split_bn(d, dy, wsplit, dx, accumulate, pieces, nullptr, stream);
+}
+
+extern "C" int svae_conv_dgrad_split_bn(const svae_conv_desc* d, const float* dy, const void* wsplit, float* dx, int accumulate,
+                                        int pieces, const svae_bn_bwd_fuse* f, void* stream) {
   if (int e = validate(d)) return e;
   SVAE_REQUIRE(dy && wsplit && dx, SVAE_ERR_ARG, "conv_dgrad_split: null pointer");
   SVAE_REQUIRE(aligned16(dy) && aligned16(wsplit) && aligned16(dx), SVAE_ERR_ALIGN, "conv_dgrad_split: pointers must be 16-byte aligned");
@@ -1358,6 +1791,11 @@ extern "C" int svae_conv_dgrad_split(const svae_conv_desc* d, const float* dy, c
   g.Kc = d->c_out; g.ldA = d->ld_out; g.ldC = d->ld_in;
   g.N = d->c_in;
   g.accumulate = accumulate;
+  if (f) {
+    SVAE_REQUIRE(f->x && f->part && (!f->scale || f->shift) && (!f->mean || f->rstd), SVAE_ERR_ARG, "conv_dgrad_split_bn: bad fuse descriptor");
+    g.stats = f->part; g.bn_x = f->x; g.bn_scale = f->scale; g.bn_shift = f->shift; g.bn_mean = f->mean; g.bn_rstd = f->rstd;
+    g.bn_alpha = f->alpha; g.bn_dalpha = f->dalpha_part;
+  }
   build_plan(g, d, /*strided=*/d->transposed != 0, d->l_in, d->l_out);
   return launch_split_gather(sa, (hipStream_t)stream, d->tile[1], pieces);
 }
@@ -1376,6 +1814,9 @@ extern "C" int svae_conv_split_tile(const svae_conv_desc* d, int kind, int* bm, 
   *bm = t.bm; *bn = t.bn; *variant = t.dma; *rmax = 0;
   if (t.dma == 8) { const int r = halo_rows(g, 128); *rmax = r <= 160 ? 160 : 264; }
   if (t.dma == 9) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 320 ? 320 : 528; }
+  if (t.dma == 10 || t.dma == 12) { const int r = halo_rows(g, 128); *rmax = r <= 160 ? 160 : 264; }
+  if (t.dma == 11) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 264 ? 264 : 320; }
+  if (t.dma == 13) { *bm = 256; *rmax = 264; }
   return SVAE_OK;
 }
 

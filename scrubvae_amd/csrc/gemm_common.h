@@ -15,6 +15,9 @@ struct GatherArgs {
   int ntaps[2];
   int base[2][SVAE_MAX_TAPS];  // li = j*sj + base
   int widx[2][SVAE_MAX_TAPS];  // weight tap of that entry
+  // the same two tables in closed form (they are arithmetic progressions: base[p][i] = base0[p] + i * bstep[p], widx likewise):
+  // kernels that walk the taps in order compute them instead of fetching them with a scalar load every stage
+  int base0[2], bstep[2], w0[2], wstep[2];
   int blocks_m[2];
   int Lin, Lout, sj, n_phase;
   int Kc;  // reduction channels per tap, multiple of 16
@@ -26,8 +29,20 @@ struct GatherArgs {
   // [z*nk/ksplit, (z+1)*nk/ksplit) and writes its partial tile to slab[z][m][N]; splitk_reduce adds them in z order
   int ksplit;
   float* slab;
-  // split-bf16 gather kernels: per-row-tile BatchNorm statistics of the written values, [row tiles][2][N] (NULL: off)
+  // split-bf16 gather kernels: per-row-tile BatchNorm sums of the written values, [row tiles][2][N] (NULL: off).
+  // bn_x == NULL: forward statistics (sum v, sum v^2).  bn_x != NULL: the launch writes the gradient dy with respect to the
+  // OUTPUT of a BatchNorm + PReLU / tanh stage whose saved input is bn_x (same row layout as C): the sums are the backward's
+  // (sum du, sum du * xhat), du = dy * act'(bn_x * scale + shift), xhat = (bn_x - mean) * rstd; scale / shift / mean may be NULL
+  // (bare activation); bn_alpha == NULL = tanh; bn_dalpha[blockIdx.x * gridDim.y + blockIdx.y] = sum over the tile of dy * u on
+  // the PReLU's negative side (the slope's gradient partial).
   float* stats;
+  const float* bn_x;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_rstd;
+  const float* bn_alpha;
+  float* bn_dalpha;
 };
 
 inline int validate(const svae_conv_desc* d) {
@@ -81,6 +96,20 @@ inline void build_plan(GatherArgs& g, const svae_conv_desc* d, bool strided, int
     }
   }
   for (int p = 0; p < g.n_phase; ++p) g.M[p] = (long long)d->batch * g.nj[p];
+  for (int p = 0; p < 2; ++p) {
+    g.base0[p] = g.ntaps[p] > 0 ? g.base[p][0] : 0;
+    g.w0[p] = g.ntaps[p] > 0 ? g.widx[p][0] : 0;
+    g.bstep[p] = g.ntaps[p] > 1 ? g.base[p][1] - g.base[p][0] : 0;
+    g.wstep[p] = g.ntaps[p] > 1 ? g.widx[p][1] - g.widx[p][0] : 0;
+  }
+}
+
+// true when the tap tables are the arithmetic progressions base0 + i * bstep / w0 + i * wstep (always, by construction: checked)
+inline bool plan_is_affine(const GatherArgs& g) {
+  for (int p = 0; p < g.n_phase; ++p)
+    for (int i = 0; i < g.ntaps[p]; ++i)
+      if (g.base[p][i] != g.base0[p] + i * g.bstep[p] || g.widx[p][i] != g.w0[p] + i * g.wstep[p]) return false;
+  return true;
 }
 
 // ---- tile selection.  Per-block work is MFMA-bound and co-resident blocks hide each other's

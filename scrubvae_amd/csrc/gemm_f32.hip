@@ -1114,7 +1114,7 @@ static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float*
   float* slab = (float*)ws;
   if (nsplit > 1) { g.out = slab; g.slab_stride = wsize; g.accumulate = 0; }
   else { g.out = dw; g.slab_stride = 0; g.accumulate = accumulate; }
-  SVAE_REQUIRE(pieces > 0 || (wg.bm <= 128 && wg.bn <= 128), SVAE_ERR_ARG, "conv_wgrad: tile %dx%d exists for the split-bf16 kernel only",
+  SVAE_REQUIRE(pieces > 0 || (wg.bm <= 128 && wg.bn <= 128), SVAE_ERR_SHAPE, "conv_wgrad: tile %dx%d exists for the split-bf16 kernel only",
                wg.bm, wg.bn);
   if (pieces > 0) {
     dim3 grid(d->kernel * g.ctiles, (d->c_out + wg.bn - 1) / wg.bn, nsplit);

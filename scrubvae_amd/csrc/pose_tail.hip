@@ -12,6 +12,7 @@
 // loss terms are reduced with wave shuffles.  The ~300 small torch ops the reference
 // launches for this stage become one kernel.
 #include "svae_internal.h"
+#include <cstdlib>
 
 namespace svae {
 
@@ -132,22 +133,34 @@ __device__ __forceinline__ void c6_to_mat_bwd(const float* a, const M3& dM, floa
 // so the expensive per-chain work (rotation products forward, chain-product backward) runs in parallel waves
 // over the same LDS tile; the cheap coupling steps run on wave 0 between barriers.  A single wave per workgroup
 // (the previous version) left the CU with one resident wave because the tile takes ~90 KB of LDS.
+// TR = frames per workgroup (lane = frame, TR <= 64).  Measured (MI355X, B = 4096, the round-1 layout with 104 KB of LDS per 64-frame
+// tile = ONE workgroup per CU): 64 frames 566 us, 48 frames 686 us, 32 frames 863 us -- fewer frames per workgroup leave lanes of the
+// per-chain waves idle and that costs more than the extra co-residency buys: the kernel is bound by its per-wave dependent LDS / VALU
+// chains (72 % of the wave cycles in s_waitcnt), not by HBM.  The tile below takes 75 KB (targets not staged, one root-rotation
+// buffer); a second co-resident workgroup additionally needs <= 168 VGPRs (the kernel uses 194): capping them
+// (__launch_bounds__(512, 3), 57 spilled registers) measured no faster (599 -> 636 us), so the cap is not set.  What the
+// per-frame cost really is made of -- ~12 k dependent VALU operations per frame behind scalar tree look-ups and ds_read_b32
+// operands, issued by 1.5 waves per SIMD -- is what a next round has to restructure (frames x joints parallelism inside a wave).
+template <int TR>
 __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const TailArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, nth = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int J = g.J, J3 = 3 * J, C6 = 6 * J;
   const int ldt = g.ldt, ldo = g.ldo;
-  float* tile = smem;                // [64][ldt] tanh outputs, later gradients
-  float* offs = tile + 64 * ldt;     // [64][ldo]
-  float* tg = offs + 64 * ldo;       // [64][ldo] targets -> position grads
-  float* pose = tg + 64 * ldo;       // [64][ldo] positions (relative to the chain start until phase 2)
-  float* dm0 = pose + 64 * ldo;      // [n_chains][64][9] per-chain gradient of the root rotation
-  const long long r0 = (long long)blockIdx.x * 64;
-  const int nrows = (int)((g.rows - r0) < 64 ? (g.rows - r0) : 64);
+  float* tile = smem;                // [TR][ldt] tanh outputs, later gradients
+  float* offs = tile + TR * ldt;     // [TR][ldo]
+  float* pose = offs + TR * ldo;     // [TR][ldo] positions (relative to the chain start, then absolute), then position gradients
+  float* dm0 = pose + TR * ldo;      // [TR][9] gradient of the shared root rotation, accumulated chain by chain
+  float* red = dm0 + TR * 9;         // [SVAE_MAX_CHAINS] per-wave partial sums
+  const long long r0 = (long long)blockIdx.x * TR;
+  const int nrows = (int)((g.rows - r0) < TR ? (g.rows - r0) : TR);
   const int n_chains = g.tree.n_chains;
 
-  // ---- phase 0 (all threads): stage y tile (tanh applied), offsets, targets
+  // ---- phase 0 (all threads): stage the y tile (tanh applied) and the offsets.  The targets are NOT staged: they are read once,
+  // coalesced, where the position error is formed (phase 2b) -- 17 KB of LDS less per tile, which together with the single
+  // root-rotation buffer lets TWO workgroups share a CU (75 KB each; the kernel is bound by its per-wave dependent LDS / VALU
+  // chains, so the second workgroup's waves nearly double the throughput)
   {
     const int f4_per_row = g.ld / 4;
     const int total = nrows * f4_per_row;
@@ -161,12 +174,11 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
     }
     const int tot3 = nrows * J3;
     const float* so = g.offsets + r0 * J3;
-    const float* stg = g.target + r0 * J3;
     for (int e = tid; e < tot3; e += nth) {
       const int rr = e / J3, c = e - rr * J3;
       offs[rr * ldo + c] = so[e];
-      tg[rr * ldo + c] = stg[e];
     }
+    for (int e = tid; e < TR * 9; e += nth) dm0[e] = 0.f;
   }
   __syncthreads();
   // ---- write x6d_hat / root_hat (coalesced, all threads)
@@ -187,10 +199,10 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
   }
 
   const bool active = lane < nrows;
-  float* my = tile + lane * ldt;
-  float* myo = offs + lane * ldo;
-  float* myt = tg + lane * ldo;
-  float* myp = pose + lane * ldo;
+  const int lrow = lane < TR ? lane : 0;  // (lanes past the tile are inactive; keep their pointers inside it)
+  float* my = tile + lrow * ldt;
+  float* myo = offs + lrow * ldo;
+  float* myp = pose + lrow * ldo;
   const bool do_bwd = g.dy != nullptr;
   const bool chain_wave = wave < n_chains && g.tree.chain_len[wave < n_chains ? wave : 0] >= 2;
   const int ch = wave < n_chains ? wave : 0;
@@ -222,9 +234,8 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
   }
   __syncthreads();
 
-  // ---- phase 2 (wave 0): absolute positions in chain order, JPE, direct + subtree-summed position gradients;
-  //      (wave 1, or 0 if there is only one): root loss
-  float jpe = 0.f, rl = 0.f;
+  // ---- phase 2a (wave 0): absolute positions in chain order; (wave 1, or 0 if there is only one): root loss
+  float rl = 0.f;
   if (wave == 0 && active) {
     myp[0] = 0.f; myp[1] = 0.f; myp[2] = 0.f;
     for (int c = 0; c < n_chains; ++c) {
@@ -234,21 +245,6 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
       for (int i = 1; i < cl; ++i) {
         const int j = g.tree.chain[c][i];
         myp[3 * j] += h0; myp[3 * j + 1] += h1; myp[3 * j + 2] += h2;
-      }
-    }
-    for (int c = 0; c < J3; ++c) {
-      const float d = myp[c] - myt[c];
-      jpe += d * d;
-      myt[c] = 2.f * g.jpe_scale * d;
-    }
-    if (do_bwd) {
-      for (int c = n_chains - 1; c >= 0; --c) {
-        const int cl = g.tree.chain_len[c];
-        for (int i = cl - 1; i >= 1; --i) {
-          const int j = g.tree.chain[c][i], par = g.tree.chain[c][i - 1];
-#pragma unroll
-          for (int r = 0; r < 3; ++r) myt[3 * par + r] += myt[3 * j + r];
-        }
       }
     }
   }
@@ -273,7 +269,47 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
   }
   __syncthreads();
 
+  // ---- phase 2b (all threads, coalesced): position error against the targets read straight from global memory, squared-error
+  // partial sums, and the direct position gradients written in place of the positions
+  {
+    float jpe = 0.f;
+    const int tot3 = nrows * J3;
+    const float* stg = g.target + r0 * J3;
+    float* dp = g.pose_out ? g.pose_out + r0 * J3 : nullptr;
+    for (int e = tid; e < tot3; e += nth) {
+      const int rr = e / J3, c = e - rr * J3;
+      const float pv = pose[rr * ldo + c];
+      if (dp) dp[e] = pv;
+      const float d = pv - stg[e];
+      jpe += d * d;
+      pose[rr * ldo + c] = 2.f * g.jpe_scale * d;
+    }
+    jpe = wave_sum(jpe);
+    if (lane == 0) red[wave] = jpe;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < nth / 64; ++w) t += red[w];
+    g.loss_part[blockIdx.x * 2] = t;
+  }
+  // ---- phase 2c (wave 0): subtree-summed position gradients
+  if (do_bwd && wave == 0 && active) {
+    for (int c = n_chains - 1; c >= 0; --c) {
+      const int cl = g.tree.chain_len[c];
+      for (int i = cl - 1; i >= 1; --i) {
+        const int j = g.tree.chain[c][i], par = g.tree.chain[c][i - 1];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) myp[3 * par + r] += myp[3 * j + r];
+      }
+    }
+  }
+  if (do_bwd) __syncthreads();
+
   // ---- phase 3 (wave = chain): chain-product backward; joints i >= 1 of a chain occur once as a rotation
+  M3 carry;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) carry.m[k] = 0.f;
   if (do_bwd && active && chain_wave) {
     M3 Rs[SVAE_MAX_CHAIN_LEN - 1];
     Rs[0] = M0;
@@ -286,9 +322,6 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
         Rs[i] = mul(Rs[i - 1], c6_to_mat(a6));
       }
     }
-    M3 carry;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) carry.m[k] = 0.f;
 #pragma unroll
     for (int i = SVAE_MAX_CHAIN_LEN - 1; i >= 1; --i) {
       if (i < len) {
@@ -297,7 +330,7 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int k = 0; k < 3; ++k) D.m[r * 3 + k] += myt[3 * j + r] * myo[3 * j + k];
+          for (int k = 0; k < 3; ++k) D.m[r * 3 + k] += myp[3 * j + r] * myo[3 * j + k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) a6[k] = my[6 * j + k];
         const M3 Mj = c6_to_mat(a6);
@@ -313,21 +346,23 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
         }
       }
     }
-    float* d = dm0 + (ch * 64 + lane) * 9;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) d[k] = carry.m[k];
   }
-  if (do_bwd) __syncthreads();
-  if (do_bwd && wave == 0 && active) {  // joint 0: the root rotation collects every chain's carry (in chain order)
-    M3 dM0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) dM0.m[k] = 0.f;
+  if (do_bwd) {
+    // the root rotation collects every chain's carry, chain by chain in a fixed order (one 2 KB buffer instead of one per chain)
     for (int c = 0; c < n_chains; ++c) {
-      if (g.tree.chain_len[c] < 2) continue;
-      const float* d = dm0 + (c * 64 + lane) * 9;
+      if (wave == c && chain_wave && active) {
+        float* d = dm0 + lane * 9;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) dM0.m[k] += d[k];
+        for (int k = 0; k < 9; ++k) d[k] += carry.m[k];
+      }
+      __syncthreads();
     }
+  }
+  if (do_bwd && wave == 0 && active) {  // joint 0
+    M3 dM0;
+    const float* d = dm0 + lane * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dM0.m[k] = d[k];
     float a0[6], da0[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) a0[k] = my[k];
@@ -339,30 +374,19 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
       my[k] = g.pre_tanh ? gk * (1.f - a0[k] * a0[k]) : gk;
     }
   }
-  if (wave == 0) {
-    jpe = wave_sum(jpe);
-    if (lane == 0) g.loss_part[blockIdx.x * 2] = jpe;
-  }
   if (wave == root_wave) {
     rl = wave_sum(rl);
     if (lane == 0) g.loss_part[blockIdx.x * 2 + 1] = rl;
   }
   __syncthreads();
-  if (g.pose_out != nullptr) {
-    float* dp = g.pose_out + r0 * J3;
-    for (int e = tid; e < nrows * J3; e += nth) {
-      const int rr = e / J3, c = e - rr * J3;
-      dp[e] = pose[rr * ldo + c];
-    }
-  }
   if (do_bwd) {
     const int f4_per_row = g.ld / 4;
     const int total = nrows * f4_per_row;
     float* dst = g.dy + r0 * g.ld;
     for (int e = tid; e < total; e += nth) {
       const int rr = e / f4_per_row, c = (e - rr * f4_per_row) * 4;
-      const float* s = tile + rr * ldt + c;
-      *reinterpret_cast<float4*>(dst + (long long)e * 4) = make_float4(s[0], s[1], s[2], s[3]);
+      const float* sp = tile + rr * ldt + c;
+      *reinterpret_cast<float4*>(dst + (long long)e * 4) = make_float4(sp[0], sp[1], sp[2], sp[3]);
     }
   }
 }
@@ -467,7 +491,19 @@ __global__ __launch_bounds__(256) void rot_loss_kernel(const float* __restrict__
 
 using namespace svae;
 
-extern "C" int svae_tail_blocks(long long rows) { return (int)((rows + 63) / 64); }
+// frames per workgroup of the tail kernel: 64 (75 KB of LDS: two workgroups per CU); SVAE_TAIL_ROWS=64|48|32 overrides it for experiments
+// (fewer frames per workgroup measured slower: idle lanes in the per-chain waves cost more than the extra co-residency buys)
+static int tail_rows() {
+  static int tr = 0;
+  if (tr == 0) {
+    const char* e = getenv("SVAE_TAIL_ROWS");
+    const int v = e ? atoi(e) : 64;
+    tr = (v == 64 || v == 48 || v == 32) ? v : 64;
+  }
+  return tr;
+}
+
+extern "C" int svae_tail_blocks(long long rows) { const int tr = tail_rows(); return (int)((rows + tr - 1) / tr); }
 
 extern "C" int svae_pose_tail(const float* y, int ld, const float* offsets, const float* target_pose, const float* root,
                               const float* arena_host, const svae_tree* tree, float jpe_scale, float root_scale,
@@ -508,15 +544,21 @@ extern "C" int svae_pose_tail(const float* y, int ld, const float* offsets, cons
   g.jpe_scale = jpe_scale; g.root_scale = root_scale;
   g.tree = *tree;
   const int n_waves = tree->n_chains >= 2 ? tree->n_chains : 2;
-  const size_t smem = (size_t)(64 * g.ldt + 3 * 64 * g.ldo + tree->n_chains * 64 * 9) * sizeof(float);
+  const int tr = tail_rows();
+  const size_t smem = (size_t)(tr * g.ldt + 2 * tr * g.ldo + tr * 9 + SVAE_MAX_CHAINS) * sizeof(float);
   SVAE_REQUIRE(smem <= 160 * 1024, SVAE_ERR_SHAPE, "pose_tail: LDS tile %zu B exceeds 160 KiB", smem);
   static bool attr_set = false;
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute((const void*)pose_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)pose_tail_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pose_tail_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pose_tail_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SVAE_REQUIRE(e == hipSuccess, SVAE_ERR_LAUNCH, "pose_tail: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(pose_tail_kernel, dim3(svae_tail_blocks(rows)), dim3(64 * n_waves), smem, (hipStream_t)stream, g);
+  const dim3 grid(svae_tail_blocks(rows)), block(64 * n_waves);
+  if (tr == 64) hipLaunchKernelGGL(pose_tail_kernel<64>, grid, block, smem, (hipStream_t)stream, g);
+  else if (tr == 48) hipLaunchKernelGGL(pose_tail_kernel<48>, grid, block, smem, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(pose_tail_kernel<32>, grid, block, smem, (hipStream_t)stream, g);
   return check_launch("pose_tail");
 }
 

@@ -504,15 +504,41 @@ class ResVAE(nn.Module):
         ops.affine_prelu_fwd(x, scale, shift, act.weight, out, rows, Cp, Cp)
         return out
 
-    def _bn_act_bwd(self, tag, dy, x, bn: BatchNormP, act: PReLUP, rows, dx, acc):
+    def _dgrad_into_bn(self, cv, dy, w, dx, accumulate, tag, x, act, bare=False):
+        """Data-gradient launch whose output `dx` is the gradient with respect to the OUTPUT of the BatchNorm + activation stage
+        `tag` (saved input `x`): where the launch runs a split-bf16 kernel, the first pass of that stage's backward (sum du,
+        sum du * xhat, slope partial) comes out of its epilogue.  Returns what _bn_act_bwd needs to skip its own pass, or None."""
+        from .._lib import BnBwdFuse
+        cv.tune_dgrad(dy, w)
+        n, cb = cv.dgrad_stats_tiles()
+        if n == 0 or x.shape[-1] != cv.desc.ld_in:
+            cv.dgrad(dy, w, dx, accumulate=accumulate)
+            return None
+        Cp = cv.c_in_p
+        part = self._buf(f"bn.tpart.{n}.{Cp}", (n, 2, Cp))
+        dap = self._buf(f"bn.tdap.{n * cb}", (n * cb,))
+        f = BnBwdFuse()
+        f.x, f.part = x.data_ptr(), part.data_ptr()
+        if not bare:
+            f.scale, f.shift = self._buf(tag + ".scale", (Cp,)).data_ptr(), self._buf(tag + ".shift", (Cp,)).data_ptr()
+            f.mean, f.rstd = self._buf(tag + ".mean", (Cp,)).data_ptr(), self._buf(tag + ".rstd", (Cp,)).data_ptr()
+        f.alpha = None if act.weight is None else act.weight.data_ptr()
+        f.dalpha_part = dap.data_ptr()
+        cv.dgrad(dy, w, dx, accumulate=accumulate, fuse=f)
+        return part, n, dap
+
+    def _bn_act_bwd(self, tag, dy, x, bn: BatchNormP, act: PReLUP, rows, dx, acc, fused=None):
         Cp = pad16(bn.c)
-        nch = ops.bn_chunks(rows)
-        part = self._buf(f"bn.part.{nch}.{Cp}", (nch, 2, Cp))
-        dap = self._buf(f"bn.dap.{nch}.{Cp}", (nch * ((Cp + 63) // 64),))
         scale, shift = self._buf(tag + ".scale", (Cp,)), self._buf(tag + ".shift", (Cp,))
         mean, rstd = self._buf(tag + ".mean", (Cp,)), self._buf(tag + ".rstd", (Cp,))
         sums = self._buf(tag + ".dsums", (2, Cp))
-        ops.affine_prelu_bwd_partial(dy, x, scale, shift, mean, rstd, act.weight, rows, Cp, Cp, part, dap)
+        if fused is not None:  # the launch that produced dy already summed (du, du * xhat) per tile
+            part, nch, dap = fused
+        else:
+            nch = ops.bn_chunks(rows)
+            part = self._buf(f"bn.part.{nch}.{Cp}", (nch, 2, Cp))
+            dap = self._buf(f"bn.dap.{nch}.{Cp}", (nch * ((Cp + 63) // 64),))
+            ops.affine_prelu_bwd_partial(dy, x, scale, shift, mean, rstd, act.weight, rows, Cp, Cp, part, dap)
         count = rows
         if self.world_size > 1 and self.sync_bn:
             ops.bn_reduce_partials(part, nch, Cp, sums)
@@ -522,7 +548,7 @@ class ResVAE(nn.Module):
             gl.copy_(sums)
             self._allreduce(gl)
             ops.affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, bn.weight, act.weight, gl, rows * self.world_size,
-                                       dx, rows, Cp, Cp, None, None, slope_grad(act), dap, nch, acc)
+                                       dx, rows, Cp, Cp, None, None, slope_grad(act), dap, dap.numel(), acc)
             if acc:
                 ops.axpy(1.0, sums[0], bn.bias.grad)
                 ops.axpy(1.0, sums[1], bn.weight.grad)
@@ -532,7 +558,7 @@ class ResVAE(nn.Module):
         else:
             ops.bn_bwd_reduce(part, nch, Cp, sums, bn.weight.grad, bn.bias.grad, slope_grad(act), dap, dap.numel(), acc)
             ops.affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, bn.weight, act.weight, sums, count, dx, rows, Cp, Cp,
-                                       None, None, None, dap, nch, acc)
+                                       None, None, None, dap, dap.numel(), acc)
         return dx
 
     # ------------------------------------------------------------------ forward pieces
@@ -883,7 +909,12 @@ class ResVAE(nn.Module):
         cvo = self._conv("dec.out", dec.conv_out, B, lens[-1])
         self._wgrad(cvo, d_in_last, dy, dec.conv_out, acc)
         g = self._buf("g.dec.top", (B * lens[-1], pad16(ch[0])))
-        cvo.dgrad(dy, dec.conv_out.weight, g)
+        nd = len(dec.res_layers)
+        # fz[tag]: first-pass sums of BatchNorm stage `tag`'s backward that came out of the epilogue of the data-gradient launch
+        # which produced its incoming gradient (absent: _bn_act_bwd runs its own pass over dy and x)
+        fz = {}
+        fz[f"dec.{nd - 1}.bn2"] = self._dgrad_into_bn(cvo, dy, dec.conv_out.weight, g, False, f"dec.{nd - 1}.bn2",
+                                                       self._buf(f"dec.{nd - 1}.s", (B * lens[-1], pad16(ch[0]))), dec.res_layers[nd - 1].add[1])
         for j in range(len(dec.res_layers) - 1, -1, -1):
             blk = dec.res_layers[j]
             t = f"dec.{j}"
@@ -896,7 +927,7 @@ class ResVAE(nn.Module):
             d_in = self._buf(f"dec.{j - 1}.a", (B * L, cv1.c_in_p)) if j > 0 else self._buf("dec.f", (B, L * cv1.c_in_p)).view(B * L, cv1.c_in_p)
             s = self._buf(t + ".s", (B * Lo, cv2.c_out_p))
             g_s = self._buf("g." + t + ".s", (B * Lo, cv2.c_out_p))
-            self._bn_act_bwd(t + ".bn2", g, s, blk.add[0], blk.add[1], B * Lo, g_s, acc)
+            self._bn_act_bwd(t + ".bn2", g, s, blk.add[0], blk.add[1], B * Lo, g_s, acc, fz.get(t + ".bn2"))
             up = self._buf(t + ".up", (B * 2 * L, cv1.c_in_p))
             t0a = self._buf(t + ".t0a", (B * L, cv1.c_out_p))
             self._wgrad(cvs, up, g_s, sk, acc)
@@ -910,13 +941,18 @@ class ResVAE(nn.Module):
 
             self._fork(skip_bwd, k=1)  # skip branch concurrently with the residual branch below
             g_t0a = self._buf("g." + t + ".t0a", (B * L, cv1.c_out_p))
-            cv2.dgrad(g_s, ct2.weight, g_t0a)
             t0 = self._buf(t + ".t0", (B * L, cv1.c_out_p))
+            f1 = self._dgrad_into_bn(cv2, g_s, ct2.weight, g_t0a, False, t + ".bn1", t0, act1)
             g_t0 = self._buf("g." + t + ".t0", (B * L, cv1.c_out_p))
-            self._bn_act_bwd(t + ".bn1", g_t0a, t0, bn1, act1, B * L, g_t0, acc)
+            self._bn_act_bwd(t + ".bn1", g_t0a, t0, bn1, act1, B * L, g_t0, acc, f1)
             self._wgrad(cv1, d_in, g_t0, ct1, acc)
             self._join_side(1)
-            cv1.dgrad(g_t0, ct1.weight, g_d, accumulate=True)
+            if j > 0:  # g_d is the gradient behind the previous block's closing BatchNorm + activation
+                pt = f"dec.{j - 1}"
+                fz[pt + ".bn2"] = self._dgrad_into_bn(cv1, g_t0, ct1.weight, g_d, True, pt + ".bn2", self._buf(pt + ".s", (B * L, cv1.c_in_p)),
+                                                      dec.res_layers[j - 1].add[1])
+            else:
+                cv1.dgrad(g_t0, ct1.weight, g_d, accumulate=True)
             g = g_d
         # ---- fc_in
         zc = st["zc"]
@@ -967,7 +1003,7 @@ class ResVAE(nn.Module):
             a_in = self._buf(f"enc.{i - 1}.a", (B * L, cv0.c_in_p)) if i > 0 else self._buf("enc.a0", (B * L, cv0.c_in_p))
             s = self._buf(t + ".s", (B * Lo, cv3.c_out_p))
             g_s = self._buf("g." + t + ".s", (B * Lo, cv3.c_out_p))
-            self._bn_act_bwd(t + ".bn2", g, s, blk.add[0], blk.add[1], B * Lo, g_s, acc)
+            self._bn_act_bwd(t + ".bn2", g, s, blk.add[0], blk.add[1], B * Lo, g_s, acc, fz.get(t + ".bn2"))
             r0a = self._buf(t + ".r0a", (B * Lo, cv0.c_out_p))
             self._wgrad(cvs, a_in, g_s, blk.skip, acc)
             self._wgrad(cv3, r0a, g_s, conv3, acc)
@@ -978,13 +1014,19 @@ class ResVAE(nn.Module):
             g_a = self._buf("g." + t + ".in", (B * L, cv0.c_in_p))
             self._fork(lambda cvs=cvs, g_s=g_s, g_a=g_a, w=blk.skip.weight: cvs.dgrad(g_s, w, g_a), k=1)
             g_r0a = self._buf("g." + t + ".r0a", (B * Lo, cv0.c_out_p))
-            cv3.dgrad(g_s, conv3.weight, g_r0a)
             r0 = self._buf(t + ".r0", (B * Lo, cv0.c_out_p))
+            f1 = self._dgrad_into_bn(cv3, g_s, conv3.weight, g_r0a, False, t + ".bn1", r0, act1)
             g_r0 = self._buf("g." + t + ".r0", (B * Lo, cv0.c_out_p))
-            self._bn_act_bwd(t + ".bn1", g_r0a, r0, bn1, act1, B * Lo, g_r0, acc)
+            self._bn_act_bwd(t + ".bn1", g_r0a, r0, bn1, act1, B * Lo, g_r0, acc, f1)
             self._wgrad(cv0, a_in, g_r0, conv0, acc)
             self._join_side(1)
-            cv0.dgrad(g_r0, conv0.weight, g_a, accumulate=True)
+            if i > 0:  # g_a is the gradient behind the previous block's closing BatchNorm + activation
+                pt = f"enc.{i - 1}"
+                fz[pt + ".bn2"] = self._dgrad_into_bn(cv0, g_r0, conv0.weight, g_a, True, pt + ".bn2", self._buf(pt + ".s", (B * L, cv0.c_in_p)),
+                                                      enc.res_layers[i - 1].add[1])
+            else:      # ... behind the bare activation after conv_in
+                fz["enc.in"] = self._dgrad_into_bn(cv0, g_r0, conv0.weight, g_a, True, "enc.in", self._buf("enc.c_in", (B * L, cv0.c_in_p)),
+                                                   enc.activation, bare=True)
             g = g_a
             if self.world_size > 1 and (enc_cut - self._enc_cuts[i]) * 4 >= self.bucket_min_bytes:
                 # data-parallel: this block (and the heads / blocks above it) is final -> next bucket
@@ -993,13 +1035,16 @@ class ResVAE(nn.Module):
         # ---- conv_in (bare PReLU in front)
         C0 = pad16(ch[0])
         c0 = self._buf("enc.c_in", (rows, C0))
-        nch = ops.bn_chunks(rows)
-        part = self._buf(f"bn.part.{nch}.{C0}", (nch, 2, C0))
-        dap = self._buf(f"bn.dap.{nch}.{C0}", (nch * ((C0 + 63) // 64),))
-        ops.affine_prelu_bwd_partial(g, c0, None, None, None, None, enc.activation.weight, rows, C0, C0, part, dap)
+        if fz.get("enc.in") is not None:  # the slope's partials came out of the last data-gradient launch
+            dap = fz["enc.in"][2]
+        else:
+            nch = ops.bn_chunks(rows)
+            part = self._buf(f"bn.part.{nch}.{C0}", (nch, 2, C0))
+            dap = self._buf(f"bn.dap.{nch}.{C0}", (nch * ((C0 + 63) // 64),))
+            ops.affine_prelu_bwd_partial(g, c0, None, None, None, None, enc.activation.weight, rows, C0, C0, part, dap)
         g_c0 = self._buf("g.enc.c_in", (rows, C0))
         ops.affine_prelu_bwd_apply(g, c0, None, None, None, None, None, enc.activation.weight, None, 1.0, g_c0, rows, C0, C0,
-                                   None, None, slope_grad(enc.activation), dap, nch, acc)
+                                   None, None, slope_grad(enc.activation), dap, dap.numel(), acc)
         x_in = self._buf("x_in", (rows, pad16(self.in_channels)))
         cvi = self._conv("enc.conv_in", enc.conv_in, B, W)
         self._wgrad(cvi, x_in, g_c0, enc.conv_in, acc)

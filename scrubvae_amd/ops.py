@@ -149,7 +149,9 @@ SPLIT_MIN_FLOPS = float(os.environ.get("SVAE_SPLIT_MIN_FLOPS", 2e9))
 _SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2128064, 3128128, 3128064)
                        + (4128128, 4128064, 4064128) + tuple(5000000 + c for c in _TILES)
                        + (6128128, 6128064, 6064128) + tuple(7000000 + c for c in _TILES) + (8128128, 8128064)
-                       + (9128128, 9128064))  # 9: halo kernel on 256-row tiles (the row field of the code stays 128)
+                       + (9128128, 9128064)  # 9: halo kernel on 256-row tiles (the row field of the code stays 128)
+                       + (10128128, 10128064, 11128128, 11128064)  # 10 / 11: wave-specialised halo kernel, 128- / 256-row tiles
+                       + (12128128, 12128064, 13128128, 13128064))  # 12 / 13: the same with three weight-tile buffers
 _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2, 1"}
 # 1BBBNNN: single LDS buffer; 256-edge tiles: 8 waves, half the operand bytes per FLOP through the vector-memory path
 _WGRAD_BIG = (256256, 256128, 128256)
@@ -254,6 +256,7 @@ class Conv:
         self._ws_bytes = None
         self.__dict__.pop("_names", None)
         self.__dict__.pop("_stats_tiles", None)
+        self.__dict__.pop("_dstats_tiles", None)
 
     def _tune(self, kind, run):
         """run(): launches this conv once with scratch outputs.  Picks the kernel family (for a
@@ -322,6 +325,8 @@ class Conv:
                 v = v.value
                 if v in (8, 9):
                     names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {kp}, 4, 2, {rm.value}>"
+                elif v in (10, 11, 12, 13):
+                    names[kind] = f"gather_halo_ws_bf16s_kernel<{bm.value}, {bn.value}, {kp}, 4, 2, {rm.value}, 0, false, {3 if v >= 12 else 2}>"
                 elif v >= 4:
                     cw = "2, 2" if v in (5, 7) else ("4, 2" if bm.value == 128 else "2, 4")
                     names[kind] = f"gather_gemm_bf16s_ws_kernel<{bm.value}, {bn.value}, {kp}, {cw}, {2 if v < 6 else 3}, 0>"
@@ -385,11 +390,25 @@ class Conv:
                                                      _stream()), "conv_fwd_ws")
         return check(_lib.lib().svae_conv_fwd(C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), acc, _stream()), "conv_fwd")
 
-    def _launch_dgrad(self, dy, w, dx, acc):
+    def dgrad_stats_tiles(self):
+        """(row tiles, column blocks) of the data-gradient launch when its kernel can emit the sums of a BatchNorm + activation
+        backward from its epilogue (split-bf16 gather kernels), else (0, 0).  Valid once the tile choice is fixed (tune_dgrad)."""
+        if not FUSE_BN_STATS or not self._kind_pieces("dgrad") or "dgrad" not in self.__dict__.get("_tuned", ()):
+            return 0, 0
+        r = self.__dict__.get("_dstats_tiles")
+        if r is None:
+            cb = C.c_int()
+            n = int(_lib.lib().svae_conv_dgrad_stats_tiles(C.byref(self.desc), C.byref(cb)))
+            r = self.__dict__["_dstats_tiles"] = (n, cb.value)
+        return r
+
+    def _launch_dgrad(self, dy, w, dx, acc, fuse=None):
         kp = self._kind_pieces("dgrad")
         if kp:
-            return check(_lib.lib().svae_conv_dgrad_split(C.byref(self.desc), _p(dy), _p(self.split_weights(w)), _p(dx),
-                                                           acc, kp, _stream()), "conv_dgrad_split")
+            return check(_lib.lib().svae_conv_dgrad_split_bn(C.byref(self.desc), _p(dy), _p(self.split_weights(w)), _p(dx),
+                                                              acc, kp, None if fuse is None else C.byref(fuse), _stream()), "conv_dgrad_split")
+        if fuse is not None:
+            raise RuntimeError("conv_dgrad: the fused BatchNorm backward sums need a split-bf16 kernel (check dgrad_stats_tiles())")
         ws = self._splitk_ws(1, dy.device)
         if ws is not None:
             return check(_lib.lib().svae_conv_dgrad_ws(C.byref(self.desc), _p(dy), _p(w), _p(dx), acc, _p(ws), ws.numel() * 4,
@@ -417,11 +436,16 @@ class Conv:
         _timed("fwd", self, self.c_out_p, lambda: self._launch_fwd(x, w, bias, y, int(accumulate), stats))
         return y
 
-    def dgrad(self, dy, w, dx, accumulate=False):
+    def tune_dgrad(self, dy, w):
         if "dgrad" not in self.__dict__.get("_tuned", ()):
             scratch = torch.empty(self.batch * self.l_in * self.desc.ld_in + 16, device=dy.device)
             self._tune("dgrad", lambda: self._launch_dgrad(dy, w, scratch, 0))
-        _timed("dgrad", self, self.c_in_p, lambda: self._launch_dgrad(dy, w, dx, int(accumulate)))
+
+    def dgrad(self, dy, w, dx, accumulate=False, fuse=None):
+        """fuse: a _lib.BnBwdFuse -- dx is the gradient wrt the output of a BatchNorm + activation stage; its backward's first
+        pass comes out of this launch's epilogue (see svae_conv_dgrad_split_bn)"""
+        self.tune_dgrad(dy, w)
+        _timed("dgrad", self, self.c_in_p, lambda: self._launch_dgrad(dy, w, dx, int(accumulate), fuse))
         return dx
 
     def wgrad(self, x, dy, dw, db, ws, accumulate=False):
@@ -565,10 +589,10 @@ def affine_prelu_bwd_partial(dy, x, scale, shift, mean, rstd, alpha, rows, Cp, l
 
 
 def affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, gamma, alpha, sums, count, dx, rows, Cp, ld,
-                           dgamma, dbeta, dalpha, dalpha_part, n_chunks, accumulate):
+                           dgamma, dbeta, dalpha, dalpha_part, n_parts, accumulate):
     check(_lib.lib().svae_affine_prelu_bwd_apply(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(gamma), _p(alpha),
                                                  _p(sums), float(count), _p(dx), rows, Cp, ld, _p(dgamma), _p(dbeta), _p(dalpha),
-                                                 _p(dalpha_part), n_chunks, int(accumulate), _stream()), "affine_prelu_bwd_apply")
+                                                 _p(dalpha_part), n_parts, int(accumulate), _stream()), "affine_prelu_bwd_apply")
 
 
 def upsample2_fwd(x, y, batch, l_in, Cp, ld):

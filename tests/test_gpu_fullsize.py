@@ -9,11 +9,16 @@ on exactly the kernel mix `bench.py` times, against the CPU oracle's `train_step
 
 Reference lines: trainer.py:126-167 (the step), losses.py:182-324, get/model.py:4-18.
 
-Gates (fp32 tolerances of DESIGN.md 2): outputs 2e-5 max-norm relative, every loss term 1e-4 relative, each gradient
-tensor 5e-2 in the scale-aware max-norm of test_oracle_golden (denominator max(|g|) + 1e-3 of the global gradient
-scale), the total gradient norm 1e-3, and the parameters after the fused AdamW step within one sign-flip of Adam's
-first update (2.5 lr) of the oracle's.  The oracle at these sizes costs ~1.5 s / ~8 s of host time.
+Gates (fp32 tolerances of DESIGN.md 2): outputs 2e-5 max-norm relative and every loss term 1e-4 relative against the fp32
+oracle.  Gradients are judged against the oracle run in fp64 (the truth: the reference's own fp32 gradients sit 1e-3 -- whole
+vector -- to 2e-2 -- PReLU slopes, cancellation-prone sums over millions of terms -- away from it at these sizes): each tensor
+within 5e-2 of the truth in the scale-aware max-norm of test_oracle_golden (denominator max(|g|) + 1e-3 of the global gradient
+scale) and within 5e-2 + the fp32 oracle's own error of the fp32 oracle; the whole gradient vector no further from the truth than
+1.5x the fp32 oracle is (measured 9.0e-4 vs 1.1e-3 at B=1024, 1.1e-3 vs 1.5e-3 at B=4096); the total gradient norm within 1e-3 of
+both; the parameters after the fused AdamW step within one sign-flip of Adam's first update (2.5 lr) of the oracle's.  The
+oracles cost ~1 + 3 s (B=1024) and ~8 + 20 s (B=4096) of host time.
 """
+import dataclasses
 import pytest
 import torch
 
@@ -43,6 +48,11 @@ def _run(B, full, precision, seed):
     eps = torch.randn(B, cfg.z_dim, generator=g)
     perm = {k: torch.randperm(B, generator=g) for k in cfg.method.get("adversarial_net", [])}
     bl_o, g_o, sd_o, out_o = O.train_step(sd, cfg, data, ls, eps, adv_perm=perm, lr=LR)
+    c64 = dataclasses.replace(cfg, arena_size=ARENA.double())
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    d64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in data.items()}
+    _, g64, _, _ = O.train_step(sd64, c64, d64, ls, eps.double(), adv_perm=perm, lr=LR)
+    del sd64, d64
     keep = ops.PRECISION
     ops.set_precision(precision)
     tuned_before = set(ops.TUNED_LOG)
@@ -71,27 +81,33 @@ def _run(B, full, precision, seed):
         ops.set_precision(keep)
     # the kernel mix is the benchmark's: every layer found its entry in the shipped tile table (nothing was tuned here)
     assert set(ops.TUNED_LOG) == tuned_before, sorted(set(ops.TUNED_LOG) - tuned_before)
+    assert all(cv.desc.tile[0] != 0 for cv in model._convs.values() if cv.flops >= ops.AUTOTUNE_MIN_FLOPS)
     assert any("gather_halo_bf16s_kernel" in n for n in names) and any("wgrad_gemm_bf16s_kernel<256" in n for n in names), names
     for k in outs:
         assert rel(outs[k].reshape(-1), out_o[k].detach().reshape(-1)) < 2e-5, k
     for k in bl_o:
         assert rel(bl[k].detach().cpu(), bl_o[k]) < 1e-4, (k, float(bl[k]), float(bl_o[k]))
-    gmax = max(float(x.abs().max()) for x in g_o.values())
-    worst = ("", 0.0)
-    for n, x in g_o.items():
-        dd = float((grads[n] - x).abs().max()) / (float(x.abs().max()) + 1e-3 * gmax)
-        if dd > worst[1]:
-            worst = (n, dd)
-        assert dd < 5e-2, (n, dd)
-    gn_o = torch.sqrt(sum((x.double() ** 2).sum() for x in g_o.values()))
-    gn_h = torch.sqrt(sum((grads[n].double() ** 2).sum() for n in g_o))
-    assert rel(gn_h, gn_o) < 1e-3, (float(gn_h), float(gn_o))
-    assert rel(gn.cpu().double(), gn_o) < 1e-3  # clip_grad_norm_'s device-side norm is the same number
-    # relative error of the whole gradient vector (not a gate of the reference's API, but the number DESIGN.md quotes)
-    num = torch.sqrt(sum(((grads[n].double() - x.double()) ** 2).sum() for n, x in g_o.items()))
-    print(f"\n[B={B} full={full} {precision}] worst tensor {worst[0]} {worst[1]:.2e}; |g_hip - g_oracle| / |g_oracle| = {float(num / gn_o):.2e}; "
-          f"grad norm {float(gn_h):.6g} vs {float(gn_o):.6g}")
-    assert float(num / gn_o) < 5e-3
+    gmax = max(float(x.abs().max()) for x in g64.values())
+    worst = ("", 0.0, 0.0)
+    for n, t in g64.items():
+        den = float(t.abs().max()) + 1e-3 * gmax
+        e_hip = float((grads[n].double() - t).abs().max()) / den
+        e_cpu = float((g_o[n].double() - t).abs().max()) / den
+        e_pair = float((grads[n] - g_o[n]).abs().max()) / (float(g_o[n].abs().max()) + 1e-3 * gmax)
+        if e_hip > worst[1]:
+            worst = (n, e_hip, e_cpu)
+        assert e_hip < 5e-2, (n, e_hip, e_cpu)
+        assert e_pair < 5e-2 + e_cpu, (n, e_pair, e_cpu)
+    nrm = lambda ts: torch.sqrt(sum((x.double() ** 2).sum() for x in ts))
+    gn64 = nrm(g64.values())
+    gn_o, gn_h = nrm(g_o.values()), nrm([grads[n] for n in g64])
+    assert rel(gn_h, gn64) < 1e-3 and rel(gn_h, gn_o) < 1e-3, (float(gn_h), float(gn_o), float(gn64))
+    assert rel(gn.cpu().double(), gn64) < 1e-3  # clip_grad_norm_'s device-side norm is the same number
+    v_hip = float(nrm([grads[n].double() - g64[n] for n in g64]) / gn64)
+    v_cpu = float(nrm([g_o[n].double() - g64[n] for n in g64]) / gn64)
+    print(f"\n[B={B} full={full} {precision}] |g_hip - g_64| / |g_64| = {v_hip:.2e} (fp32 CPU oracle: {v_cpu:.2e}); worst tensor {worst[0]} "
+          f"{worst[1]:.2e} (oracle {worst[2]:.2e}); grad norm {float(gn_h):.6g} vs fp64 {float(gn64):.6g}")
+    assert v_hip < 1.5 * v_cpu + 2e-4, (v_hip, v_cpu)
     for n in O.trainable_names(sd):
         dv = float((new_sd[n] - sd_o[n]).abs().max())
         assert dv <= 2.5 * LR + 1e-5 * float(sd_o[n].abs().max()), (n, dv)

@@ -153,7 +153,7 @@ def test_bn_prelu_fwd_bwd(ops, rows, Cc):
     ops.bn_reduce_partials(part, nch, Cc, sums)
     dxd = torch.empty_like(xd)
     dg, db, da = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda"), torch.zeros(1, device="cuda")
-    ops.affine_prelu_bwd_apply(dyd, xd, scale, shift, mean, rstd, gd, ad, sums, rows, dxd, rows, Cc, Cc, dg, db, da, dap, nch, False)
+    ops.affine_prelu_bwd_apply(dyd, xd, scale, shift, mean, rstd, gd, ad, sums, rows, dxd, rows, Cc, Cc, dg, db, da, dap, dap.numel(), False)
     assert relerr(dxd.cpu(), x.grad) < 2e-5
     assert relerr(dg.cpu(), gamma.grad) < 2e-5 and relerr(db.cpu(), beta.grad) < 2e-5
     assert relerr(da.cpu(), alpha.grad) < 2e-5
@@ -187,7 +187,7 @@ def test_bn_tanh_fwd_bwd(ops, rows, Cc):
     ops.bn_reduce_partials(part, nch, Cc, sums)
     dxd = torch.empty_like(xd)
     dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
-    ops.affine_prelu_bwd_apply(dyd, xd, scale, shift, mean, rstd, gd, None, sums, rows, dxd, rows, Cc, Cc, dg, db, None, dap, nch, False)
+    ops.affine_prelu_bwd_apply(dyd, xd, scale, shift, mean, rstd, gd, None, sums, rows, dxd, rows, Cc, Cc, dg, db, None, dap, dap.numel(), False)
     assert relerr(dxd.cpu(), x.grad) < 2e-5
     assert relerr(dg.cpu(), gamma.grad) < 2e-5 and relerr(db.cpu(), beta.grad) < 2e-5
     assert float(dap.abs().max()) == 0.0  # no slope, no slope-gradient partials
@@ -212,7 +212,7 @@ def test_bare_prelu_bwd(ops):
     ops.affine_prelu_bwd_partial(dyd, xd, None, None, None, None, ad, rows, Cc, Cc, part, dap)
     dxd = torch.empty_like(xd)
     da = torch.zeros(1, device="cuda")
-    ops.affine_prelu_bwd_apply(dyd, xd, None, None, None, None, None, ad, None, 1.0, dxd, rows, Cc, Cc, None, None, da, dap, nch, False)
+    ops.affine_prelu_bwd_apply(dyd, xd, None, None, None, None, None, ad, None, 1.0, dxd, rows, Cc, Cc, None, None, da, dap, dap.numel(), False)
     assert relerr(dxd.cpu(), x.grad) < 1e-6 and relerr(da.cpu(), alpha.grad) < 1e-4
 
 
@@ -420,9 +420,11 @@ def _split_cases():
     for case in CONV_CASES:
         for code in (128128, 64128, 128064, 64064, 1128128, 1064128, 1128064, 1064064, 2128128, 2128064, 3128128, 3128064,
                      4128128, 4128064, 4064128, 5128128, 5128064, 5064128, 5064064,
-                     6128128, 6128064, 6064128, 7128128, 7128064, 7064128, 7064064, 8128128, 8128064, 9128128, 9128064, 0):
+                     6128128, 6128064, 6064128, 7128128, 7128064, 7064128, 7064064, 8128128, 8128064, 9128128, 9128064,
+                     10128128, 10128064, 11128128, 11128064, 12128064, 13128064, 0):
             out.append((case, code, 3))
-        for code in (64064, 2128064, 3128128, 4128128, 5064064, 8128128, 8128064, 9128128, 9128064):  # 2 pieces: the backward pass of bf16x6b3
+        for code in (64064, 2128064, 3128128, 4128128, 5064064, 8128128, 8128064, 9128128, 9128064,
+                     10128128, 10128064, 11128128, 11128064, 12128128, 12128064, 13128128, 13128064):  # 2 pieces: the backward pass of bf16x6b3
             out.append((case, code, 2))
         out.append((case, 1128064, 1))
     return out
@@ -452,7 +454,7 @@ def test_split_gather_kernels(ops, case, code, pieces):
         cv.fwd(to_nlc(x.detach()), wd, bd, yd)
         cv.dgrad(to_nlc(dy), wd, torch.empty(B * L, cv.c_in_p, device="cuda"))
     except RuntimeError as e:
-        if code // 1000000 == 9 and "does not fit" in str(e):
+        if code // 1000000 in (9, 10, 11, 12, 13) and "does not fit" in str(e):
             pytest.skip("256-row halo image larger than LDS for this geometry (the tuner skips it the same way)")
         raise
     assert relerr(from_nlc(yd, B, cv.l_out, Cout), y.detach()) < tol * math.sqrt(Cin * k) + tol

@@ -9,12 +9,19 @@ from scrubvae_amd.get import model as get_model
 from scrubvae_amd.train.losses import get_batch_loss
 
 table = dict(ops.TILE_TABLE) if "--keep" in sys.argv else {}
+# --retune fwd@3,dgrad@2: with --keep, drop the entries of these (kind@pieces) prefixes so that they are measured again (new kernel
+# variants joined the candidate list)
+for a in list(sys.argv):
+    if a.startswith("--retune="):
+        pre = tuple(x + ":" for x in a.split("=", 1)[1].split(","))
+        table = {k: v for k, v in table.items() if not k.startswith(pre)}
+        sys.argv.remove(a)
 sys.argv = [a for a in sys.argv if a != "--keep"]
 ops.TILE_TABLE = {}
 ops.AUTOTUNE_REPS = 12
 PRECISIONS = sys.argv[1:] or ["f32", "bf16x6", "bf16x6w3", "bf16x6b3"]
 for prec, joints, batch, full in [(p, *c) for p in PRECISIONS
-                                  for c in ((23, 1024, False), (23, 1024, True), (23, 4096, False), (18, 1024, False), (23, 256, False))]:
+                                  for c in ((23, 4096, True), (23, 1024, False), (23, 1024, True), (23, 4096, False), (18, 1024, False), (23, 256, False))]:
     ops.set_precision(prec)
     data, tree = synthetic.make_batch(joints, 64, batch, seed=0, device="cuda")
     method = {"conditional": ["avg_speed_3d", "heading"], "grad_reversal": ["avg_speed_3d", "heading"], "adversarial_net": ["heading"]} if full else {}
