@@ -156,7 +156,9 @@ _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2
 # 1BBBNNN: single LDS buffer; 256-edge tiles: 8 waves, half the operand bytes per FLOP through the vector-memory path
 _WGRAD_BIG = (256256, 256128, 128256)
 _SPLIT_WGRAD_CODES = _TILES + tuple(1000000 + c for c in _TILES) + _WGRAD_BIG + tuple(1000000 + c for c in _WGRAD_BIG)
-FUSE_BN_STATS = True  # BatchNorm batch statistics from the conv GEMM's epilogue where its kernel supports it
+# BatchNorm batch statistics (forward) and first-pass backward sums from the conv GEMMs' epilogues where their kernels support it
+# (SVAE_FUSE_BN=0: the separate passes, for A/B measurements)
+FUSE_BN_STATS = os.environ.get("SVAE_FUSE_BN", "1") != "0"
 MIX_F32 = True  # a bf16x6 conv may keep the fp32 MFMA kernel for a pass where that is faster (same accuracy)
 WEIGHT_EPOCH = 0  # bumped whenever master weights may have changed (start of every model pass)
 
