@@ -11,9 +11,11 @@ windows per GPU, recon + KL only) is measured in the same run at N=1 and reporte
 JSON line (`--workload config1` makes it the headline instead).
 
 A step = forward + all configured losses + backward + grad-norm / clip + optimizer step, inputs already resident in HBM.
-Arithmetic: fp32 storage and accumulation everywhere; the large contractions run on the bf16 matrix cores with every fp32
-operand split into bf16 pieces (default `--precision bf16x6b3`: 3 pieces / 6 products forward -- outputs, losses and the
-ELBO are fp32-accurate --, 2 pieces / 3 products for the data- and weight-gradient contractions).
+Arithmetic: fp32 storage and accumulation everywhere; the large contractions run on the matrix cores with every fp32 operand
+split into 16-bit pieces (default `--precision f16x3b3`: forward = two FP16 pieces per operand, i.e. 22 of its 24 significand
+bits, and their 3 cross products -- outputs, losses and the ELBO match the fp32 CPU oracle to ~1e-7, checked in every run by
+`elbo_match` --; data- and weight-gradient contractions = two BF16 pieces / 3 products; `--precision bf16x6b3` runs the forward
+with three bf16 pieces / 6 products instead).
 Weak scaling: the per-GPU batch is fixed as N grows; every loss is normalised by the global batch and gradients are summed
 over ranks with RCCL.  BatchNorm batch statistics are per rank by default (the semantics of torch DistributedDataParallel
 around the reference model); `--sync-bn` all-reduces them so that N ranks reproduce the 1-rank step at the global batch.
@@ -43,7 +45,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
-PRODUCTS = {"f32": 1, "bf16x6": 6, "bf16x6w3": 6, "bf16x6b3": 6, "bf16x3": 3, "bf16": 1}  # matrix-core products per algorithmic multiply (fwd / dgrad)
+PRODUCTS = {"f32": 1, "bf16x6": 6, "bf16x6w3": 6, "bf16x6b3": 6, "bf16x3": 3, "bf16": 1, "f16x3b3": 3}  # matrix-core products per algorithmic multiply (fwd / dgrad)
 CHANNELS = [64, 128, 256, 512, 1024]
 WIDE6 = [64, 128, 256, 512, 1024, 2048, 4096]
 ARENA = [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]
@@ -69,10 +71,11 @@ def parse():
                     help="N>1: all-reduce the BatchNorm batch statistics (one fused buffer per BatchNorm and direction) so that N "
                          "ranks reproduce the 1-rank step at the global batch exactly; default = per-rank statistics")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph (single GPU)")
-    ap.add_argument("--precision", default=os.environ.get("SVAE_PRECISION", "bf16x6b3"), choices=list(PRODUCTS),
+    ap.add_argument("--precision", default=os.environ.get("SVAE_PRECISION", "f16x3b3"), choices=list(PRODUCTS),
                     help="arithmetic of the large contractions: f32 = fp32 MFMA; bf16x6 = fp32-accurate 3-piece split on the bf16 "
                          "matrix cores (6 products); bf16x6w3 = the same with 2 pieces / 3 products for the weight-gradient "
-                         "contractions; bf16x6b3 = 3 products for the whole backward pass, 6 for the forward; bf16x3 / bf16 = "
+                         "contractions; bf16x6b3 = 3 products for the whole backward pass, 6 for the forward; f16x3b3 = forward with two "
+                         "FP16 pieces / 3 products (22-bit operands, ~2^-22 per product), backward as bf16x6b3; bf16x3 / bf16 = "
                          "2 / 1 pieces everywhere (reduced accuracy, study only)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="timed region without the concurrent side streams (what the roofline region always uses)")
@@ -348,6 +351,12 @@ def run_workload(args, full, B, rank, world, roofline=True):
 def precision_text(p):
     if p == "f32":
         return "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+    if p == "f16x3b3":
+        return ("f16x3b3: fp32 storage and accumulation; forward contractions split every fp32 operand into TWO FP16 pieces (22 of its 24 "
+                "significand bits) and run 3 cross products on v_mfma_f32_32x32x16_f16 (~2^-22 per product: outputs, losses and the ELBO "
+                "match the fp32 CPU oracle to ~1e-6, the check is `elbo_match`); data- and weight-gradient contractions: 2 bf16 pieces / 3 "
+                "products on v_mfma_f32_32x32x16_bf16 (whole-step gradients checked against the CPU oracle at the benchmark's size, "
+                "tests/test_gpu_fullsize.py)")
     tail = {"bf16x6": " (fp32-accurate, DESIGN.md 4)",
             "bf16x6w3": " forward and data-gradient (fp32-accurate), 3 (2 pieces) for the weight-gradient contractions "
                         "(gradient error vs fp64 unchanged, DESIGN.md 4)",
@@ -380,7 +389,7 @@ def main():
             "value": head["value"], "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else f"f32 ({args.precision} split on the bf16 matrix cores)",
+            "dtype": "f32" if args.precision == "f32" else f"f32 ({args.precision} split on the {'fp16 / bf16' if 'f16x' in args.precision else 'bf16'} matrix cores)",
             "data": "synthetic",
             "config": {"workload": head["workload"], "batch_per_gpu": B, "global_batch": B * world, "window": args.window,
                        "joints": args.joints, "launch": "hipGraph replay" if args.graph else "eager launches",

@@ -109,6 +109,10 @@ typedef struct {
 int svae_conv_split_weights_batched(const svae_split_task* tasks, int n, void* stream);
 int svae_conv_fwd_split(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias,
                         float* y, int accumulate, int pieces, void* stream);
+/* pieces = SVAE_PIECES_F16X2 (forward only): two fp16 pieces per operand (22 of the 24 significand bits), three cross products --
+ * fp32-class accuracy (~2^-22 per product) at half the matrix-core work of pieces = 3; the weights' fp16 planes (of 2^10 w, undone in
+ * the epilogue) are part of the svae_conv_split_weights output.  Operands beyond fp16's range (|x| > 65504) saturate. */
+#define SVAE_PIECES_F16X2 22
 /* The same launch with the train-mode BatchNorm statistics of the conv output fused into its epilogue (nn.BatchNorm1d right
  * behind the conv, residual.py:88,112,146,173): bn_part[tile][2][c_out] = per-column (sum y, sum y^2) over the valid rows of
  * row tile `tile`, y = the value written (bias and, with accumulate, the previous content included) -- the layout of

@@ -64,6 +64,32 @@ __device__ __forceinline__ void split4(float4 v, uint2 (&out)[P]) {
   }
 }
 
+// ---- fp16 pieces (H = true, P = 2): x = h0 + h1 + O(2^-22 x), h0 = fp16(x) (11 significant bits), h1 = fp16(x - h0): two pieces hold
+// 22 of the 24 bits of an fp32 against 16 for two bf16 pieces, so the THREE cross products h0*g0 + h0*g1 + h1*g0 are accurate to
+// ~2^-22 per product -- fp32-class accuracy at half the matrix-core work of the 6-product bf16 split (the fp16 and bf16 MFMAs run at
+// the same rate).  fp16 has a narrow exponent range: operands above 65504 saturate (round-toward-zero conversion: no infinities)
+// and second pieces below 6e-5 go subnormal (absolute error <= 3e-8, negligible next to O(1) activations); the WEIGHTS, whose
+// second pieces would sit there, are scaled by 2^10 when they are split and the accumulators by 2^-10 in the epilogue (both exact).
+// Used for the forward pass only (precision "f16x3b3"): gradients span too many decades for unscaled fp16.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float F16_WSCALE = 1024.f, F16_OSCALE = 1.f / 1024.f;
+__device__ __forceinline__ unsigned pack_h2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+__device__ __forceinline__ float h2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ void split4h(float4 v, uint2 (&out)[2]) {
+  const unsigned a = pack_h2(v.x, v.y), b = pack_h2(v.z, v.w);
+  out[0].x = a;
+  out[0].y = b;
+  const float r0 = v.x - h2f((unsigned short)(a & 0xffffu)), r1 = v.y - h2f((unsigned short)(a >> 16));
+  const float r2 = v.z - h2f((unsigned short)(b & 0xffffu)), r3 = v.w - h2f((unsigned short)(b >> 16));
+  out[1].x = pack_h2(r0, r1);
+  out[1].y = pack_h2(r2, r3);
+}
+template <int P, bool H>
+__device__ __forceinline__ void split4x(float4 v, uint2 (&out)[P]) {
+  if constexpr (H) { static_assert(P == 2, "fp16 pieces: two"); split4h(v, out); }
+  else split4<P>(v, out);
+}
+
 // 16-byte chunk c of LDS row `row` (64-byte rows = 32 bf16) sits at chunk position c ^ swz(row):
 // the ds_read_b128 operand fetch of 32 consecutive rows is then conflict-free without padding
 __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
@@ -85,6 +111,22 @@ __device__ __forceinline__ f32x16 mfma_split(const uint4 (&a)[P], const uint4 (&
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gptr_t;
 
+__device__ __forceinline__ f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <int P, bool H>
+__device__ __forceinline__ f32x16 mfma_splitx(const uint4 (&a)[P], const uint4 (&b)[P], f32x16 acc) {
+  if constexpr (H) {
+#pragma unroll
+    for (int s = P - 1; s >= 0; --s)
+#pragma unroll
+      for (int i = s; i >= 0; --i) acc = mfma_f16(a[i], b[s - i], acc);
+    return acc;
+  } else {
+    return mfma_split<P>(a, b, acc);
+  }
+}
+
 constexpr int SBK = 32;  // K depth of one LDS stage: a 128-byte line of every gathered fp32 row
 
 struct SplitGatherArgs {
@@ -102,7 +144,7 @@ struct SplitGatherArgs {
 // Fixed summation order (lane rows, the two half-waves, then the WR row-waves): bit-reproducible.
 template <int MT, int NT, int WM, int WN, int WR, int BN>
 __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)[MT][NT], const long long* rowoff, int n0, int wr, int wc,
-                                              int lr, int h, float* red, int tid, int nth) {
+                                              int lr, int h, float* red, int tid, int nth, float oscale = 1.f) {
   float cs[NT], cq[NT];
   float da = 0.f;
   const bool bwd = g.bn_x != nullptr;        // uniform
@@ -128,7 +170,7 @@ __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)
         const long long off = rowoff[row];
         if (off >= 0) {
           float* dst = g.C + off + col;
-          float v = acc[mt][nt][r] + bv;
+          float v = acc[mt][nt][r] * oscale + bv;
           if (g.accumulate) v += *dst;
           *dst = v;
           if (bwd) {
@@ -186,7 +228,7 @@ __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)
 // BM x BN tile per workgroup of WR x WC waves.  NSTAGE = 2: double-buffered LDS, one barrier per
 // K stage (register prefetch two stages ahead);  NSTAGE = 1: one LDS buffer, two barriers per
 // stage, half the LDS -> more workgroups per CU hide each other's conversion / barrier phases.
-template <int BM, int BN, int P, int WR, int WC, int NSTAGE, int MINW>
+template <int BM, int BN, int P, int WR, int WC, int NSTAGE, int MINW, bool H = false>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void gather_gemm_bf16s_kernel(const SplitGatherArgs sa) {
   const GatherArgs& g = sa.g;
   constexpr int NTH = 64 * WR * WC;
@@ -298,7 +340,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void gather_gemm_bf16s_kernel(c
     for (int i = 0; i < APASS; ++i) {
       const int row = (tid >> 3) + RPP * i;
       uint2 pc[P];
-      split4<P>(ra_ok[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f), pc);
+      split4x<P, H>(ra_ok[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f), pc);
       const int off = row * ROWB + (((akq >> 1) ^ swz(row)) << 4) + ((akq & 1) << 3);
 #pragma unroll
       for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(st + p * A_PIECE + off) = pc[p];
@@ -346,7 +388,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void gather_gemm_bf16s_kernel(c
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_split<P>(av[mt], bv[nt], acc[mt][nt]);
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_splitx<P, H>(av[mt], bv[nt], acc[mt][nt]);
   };
 
   if constexpr (NSTAGE == 2) {
@@ -381,7 +423,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void gather_gemm_bf16s_kernel(c
     }
   }
 
-  tile_epilogue<MT, NT, WM, WN, WR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), tid, NTH);
+  tile_epilogue<MT, NT, WM, WN, WR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), tid, NTH, H ? F16_OSCALE : 1.f);
 }
 
 // ------------------------------------------------- gather GEMM, wave-specialised (fwd / dgrad)
@@ -393,7 +435,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void gather_gemm_bf16s_kernel(c
 // barrier per K stage, executed once per stage by both roles.
 // DBG (timing experiments only, wrong results): 1 = producers issue no global loads, 2 = producers skip the
 // split (stage the raw bits), 4 = consumers issue no MFMAs, 8 = consumers issue no LDS reads
-template <int BM, int BN, int P, int CWR, int CWC, int D, int DBG = 0>
+template <int BM, int BN, int P, int CWR, int CWC, int D, int DBG = 0, bool H = false>
 __global__ __launch_bounds__(64 * (4 + CWR * CWC)) void gather_gemm_bf16s_ws_kernel(const SplitGatherArgs sa) {
   const GatherArgs& g = sa.g;
   constexpr int WM = BM / CWR, MT = WM / 32, WN = BN / CWC, NT = WN / 32;
@@ -523,7 +565,7 @@ __global__ __launch_bounds__(64 * (4 + CWR * CWC)) void gather_gemm_bf16s_ws_ker
 #pragma unroll
           for (int p = 0; p < P; ++p) pc[p] = make_uint2(f2u(a.x) + p, f2u(a.y));
         } else {
-          split4<P>(ra_ok[S][i] ? make_float4(a.x, a.y, a.z, a.w) : make_float4(0.f, 0.f, 0.f, 0.f), pc);
+          split4x<P, H>(ra_ok[S][i] ? make_float4(a.x, a.y, a.z, a.w) : make_float4(0.f, 0.f, 0.f, 0.f), pc);
         }
         const int off = row * ROWB + (((akq >> 1) ^ swz(row)) << 4) + ((akq & 1) << 3);
 #pragma unroll
@@ -616,14 +658,14 @@ __global__ __launch_bounds__(64 * (4 + CWR * CWC)) void gather_gemm_bf16s_ws_ker
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[mt][nt][p] += __builtin_bit_cast(float, av[mt][p].x ^ bv[nt][p].y);
           } else {
-            acc[mt][nt] = mfma_split<P>(av[mt], bv[nt], acc[mt][nt]);
+            acc[mt][nt] = mfma_splitx<P, H>(av[mt], bv[nt], acc[mt][nt]);
           }
         }
     }
     __syncthreads();
   }
 
-  tile_epilogue<MT, NT, WM, WN, CWR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), ctid, 64 * CWR * CWC);
+  tile_epilogue<MT, NT, WM, WN, CWR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), ctid, 64 * CWR * CWC, H ? F16_OSCALE : 1.f);
 }
 
 // ----------------------------------------------------- gather GEMM with a halo image (fwd / dgrad)
@@ -635,7 +677,7 @@ __global__ __launch_bounds__(64 * (4 + CWR * CWC)) void gather_gemm_bf16s_ws_ker
 // that a tap reaches across a sample boundary (conv padding) hold the neighbouring sample's data
 // and are zeroed in registers by the reader.  A-side global loads, split VALU and LDS writes drop
 // by ~k.  K loop order: channel block outer, tap inner.
-template <int BM, int BN, int P, int WR, int WC, int RMAX>
+template <int BM, int BN, int P, int WR, int WC, int RMAX, bool H = false>
 __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const SplitGatherArgs sa) {
   const GatherArgs& g = sa.g;
   constexpr int NTH = 64 * WR * WC;
@@ -734,7 +776,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
     for (int i = 0; i < APASS; ++i) {
       const int r = (tid >> 3) + RPP * i;
       uint2 pc[P];
-      split4<P>(ra_ok[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f), pc);
+      split4x<P, H>(ra_ok[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f), pc);
       const int off = r * ROWB + (((akq >> 1) ^ swz(r)) << 4) + ((akq & 1) << 3);
       if ((i + 1) * RPP <= RMAX || r < RMAX) {
 #pragma unroll
@@ -837,7 +879,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_split<P>(av[ks][mt], bv[ks][nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_splitx<P, H>(av[ks][mt], bv[ks][nt], acc[mt][nt]);
   };
 
   if (ns > 0) {
@@ -861,7 +903,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
   }
   if (ns == 0) __syncthreads();  // rowoff
 
-  tile_epilogue<MT, NT, WM, WN, WR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), tid, NTH);
+  tile_epilogue<MT, NT, WM, WN, WR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), tid, NTH, H ? F16_OSCALE : 1.f);
 }
 
 // ------------------------------------------- halo-image gather GEMM, wave-specialised (fwd / dgrad)
@@ -886,7 +928,7 @@ __device__ __attribute__((aligned(16))) unsigned short halo_zero_chunk[8] = {0, 
 // an interval's matrix work (~0.7 us) is shorter than the DMA's L2 round trip (~1 us), the producers become the critical path.
 // 3: the tile of stage s + 2 is requested in interval s; the producers wait with a COUNTED vmcnt that leaves this interval's
 // requests in flight (bare s_barrier + explicit waits: __syncthreads() would drain them all).
-template <int BM, int BN, int P, int WR, int WC, int RMAX, int DBG = 0, bool PIPE = false, int NB = 2>
+template <int BM, int BN, int P, int WR, int WC, int RMAX, int DBG = 0, bool PIPE = false, int NB = 2, bool H = false>
 __global__ __launch_bounds__(64 * (WR * WC + 2)) void gather_halo_ws_bf16s_kernel(const SplitGatherArgs sa) {
   const GatherArgs& g = sa.g;
   constexpr int NCT = 64 * WR * WC;   // consumer threads
@@ -984,7 +1026,7 @@ __global__ __launch_bounds__(64 * (WR * WC + 2)) void gather_halo_ws_bf16s_kerne
       for (int i = 0; i < APASS; ++i) {
         const int r = (ptid >> 3) + RPP * i;
         uint2 pc[P];
-        split4<P>((a_row_ok[i] && ra_kq) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f), pc);
+        split4x<P, H>((a_row_ok[i] && ra_kq) ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f), pc);
         const int off = r * ROWB + (((akq >> 1) ^ swz(r)) << 4) + ((akq & 1) << 3);
         if ((i + 1) * RPP <= RMAX || r < RMAX) {
 #pragma unroll
@@ -1147,7 +1189,7 @@ __global__ __launch_bounds__(64 * (WR * WC + 2)) void gather_halo_ws_bf16s_kerne
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[mt][nt][p] += __builtin_bit_cast(float, av[ks][mt][p].x ^ bv[ks][nt][p].y);
           } else {
-            acc[mt][nt] = mfma_split<P>(av[ks][mt], bv[ks][nt], acc[mt][nt]);
+            acc[mt][nt] = mfma_splitx<P, H>(av[ks][mt], bv[ks][nt], acc[mt][nt]);
           }
         }
     };
@@ -1172,7 +1214,7 @@ __global__ __launch_bounds__(64 * (WR * WC + 2)) void gather_halo_ws_bf16s_kerne
     }
     if (ns > 0) mma(K1{});
   }
-  tile_epilogue<MT, NT, WM, WN, WR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), tid, NCT);
+  tile_epilogue<MT, NT, WM, WN, WR, BN>(g, acc, rowoff, n0, wr, wc, lr, h, reinterpret_cast<float*>(smem), tid, NCT, H ? F16_OSCALE : 1.f);
 }
 
 // ---------------------------------------------------------------------------- weight split
@@ -1180,8 +1222,10 @@ __global__ __launch_bounds__(64 * (WR * WC + 2)) void gather_halo_ws_bf16s_kerne
 //   plane(n, k) at [piece][tap][k/32][n][k%32], k zero-padded to a multiple of 32.
 //   Wf: n = c_out, k = c_in (forward)      Wd: n = c_in, k = c_out (data gradient)
 // One workgroup converts a 32 (n) x 32 (k) block; Wf goes through an LDS transpose.
+// outh != NULL (forward orientation): additionally the two fp16 piece planes of 2^10 * w, same tiling
 __device__ __forceinline__ void split_block(const float* __restrict__ w, unsigned short* __restrict__ out, int T, int Cin, int Cout,
-                                            int to_wd, long long piece_stride, int nb, int kb, int t, float (*tile)[33]) {
+                                            int to_wd, long long piece_stride, int nb, int kb, int t, float (*tile)[33],
+                                            unsigned short* __restrict__ outh = nullptr) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int N = to_wd ? Cin : Cout, K = to_wd ? Cout : Cin;
   const int KB = (K + 31) / 32;
@@ -1209,6 +1253,13 @@ __device__ __forceinline__ void split_block(const float* __restrict__ w, unsigne
     if (n >= N) continue;
     float x = v[i];
     const long long o = (((long long)t * KB + kb) * N + n) * 32 + tx;
+    if (outh != nullptr) {
+      const float xs = v[i] * F16_WSCALE;
+      const _Float16 h0 = (_Float16)xs;            // round to nearest: the residual is exact in fp32
+      const _Float16 h1 = (_Float16)(xs - (float)h0);
+      outh[o] = __builtin_bit_cast(unsigned short, h0);
+      outh[piece_stride + o] = __builtin_bit_cast(unsigned short, h1);
+    }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
       const unsigned u = p == 2 ? (pack_rne(x, 0.f) & 0xffffu) : (f2u(x) >> 16);
@@ -1219,9 +1270,10 @@ __device__ __forceinline__ void split_block(const float* __restrict__ w, unsigne
 }
 
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                                            int T, int Cin, int Cout, int to_wd, long long piece_stride) {
+                                                            int T, int Cin, int Cout, int to_wd, long long piece_stride,
+                                                            unsigned short* __restrict__ outh) {
   __shared__ float tile[32][33];
-  split_block(w, out, T, Cin, Cout, to_wd, piece_stride, blockIdx.x, blockIdx.y, blockIdx.z, tile);
+  split_block(w, out, T, Cin, Cout, to_wd, piece_stride, blockIdx.x, blockIdx.y, blockIdx.z, tile, outh);
 }
 
 // all convolutions of a model in ONE launch: block -> (task, direction, tap, k block, n block)
@@ -1249,7 +1301,8 @@ __global__ __launch_bounds__(256) void split_weights_batched_kernel(const SplitT
   const int nblocks = to_wd ? bi : bo;
   const int kb = b / nblocks, nb = b - kb * nblocks;
   const long long pf = (long long)T * bi * 32 * Cout, pd = (long long)T * bo * 32 * Cin;
-  split_block(ts.w[k], ts.out[k] + (to_wd ? 3 * pf : 0), T, Cin, Cout, to_wd, to_wd ? pd : pf, nb, kb, t, tile);
+  split_block(ts.w[k], ts.out[k] + (to_wd ? 3 * pf : 0), T, Cin, Cout, to_wd, to_wd ? pd : pf, nb, kb, t, tile,
+              to_wd ? nullptr : ts.out[k] + 3 * pf + 3 * pd);
 }
 
 // ------------------------------------------------------------------------------ weight grad
@@ -1490,7 +1543,7 @@ int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, in
 }
 
 // ------------------------------------------------------------------------------ host side
-// layout of the split-weight buffer: [Wf: 3 planes][Wd: 3 planes], plane sizes in elements
+// layout of the split-weight buffer: [Wf: 3 bf16 planes][Wd: 3 bf16 planes][Wfh: 2 fp16 planes of 2^10 w], plane sizes in elements
 static inline long long plane_f(const svae_conv_desc* d) { return (long long)d->kernel * ((d->c_in + 31) / 32) * 32 * d->c_out; }
 static inline long long plane_d(const svae_conv_desc* d) { return (long long)d->kernel * ((d->c_out + 31) / 32) * 32 * d->c_in; }
 
@@ -1498,6 +1551,7 @@ template <int BM, int BN, int WR, int WC, int NSTAGE, int MINW>
 static void launch_split_p(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces) {
   const dim3 block(64 * WR * WC);
   if (pieces == 3) hipLaunchKernelGGL((gather_gemm_bf16s_kernel<BM, BN, 3, WR, WC, NSTAGE, MINW>), grid, block, 0, st, sa);
+  else if (pieces == SVAE_PIECES_F16X2) hipLaunchKernelGGL((gather_gemm_bf16s_kernel<BM, BN, 2, WR, WC, NSTAGE, MINW, true>), grid, block, 0, st, sa);
   else if (pieces == 2) hipLaunchKernelGGL((gather_gemm_bf16s_kernel<BM, BN, 2, WR, WC, NSTAGE, MINW>), grid, block, 0, st, sa);
   else hipLaunchKernelGGL((gather_gemm_bf16s_kernel<BM, BN, 1, WR, WC, NSTAGE, MINW>), grid, block, 0, st, sa);
 }
@@ -1506,6 +1560,7 @@ template <int BM, int BN, int CWR, int CWC, int D>
 static void launch_split_ws(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces) {
   const dim3 block(64 * (4 + CWR * CWC));
   if (pieces == 3) hipLaunchKernelGGL((gather_gemm_bf16s_ws_kernel<BM, BN, 3, CWR, CWC, D>), grid, block, 0, st, sa);
+  else if (pieces == SVAE_PIECES_F16X2) hipLaunchKernelGGL((gather_gemm_bf16s_ws_kernel<BM, BN, 2, CWR, CWC, D, 0, true>), grid, block, 0, st, sa);
   else if (pieces == 2) hipLaunchKernelGGL((gather_gemm_bf16s_ws_kernel<BM, BN, 2, CWR, CWC, D>), grid, block, 0, st, sa);
   else hipLaunchKernelGGL((gather_gemm_bf16s_ws_kernel<BM, BN, 1, CWR, CWC, D>), grid, block, 0, st, sa);
 }
@@ -1545,9 +1600,12 @@ static int halo_rows(const GatherArgs& g, int bm) {
 
 template <int BN>
 static int launch_halo(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
-  if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
+  if (pieces != 3 && pieces != 2 && pieces != SVAE_PIECES_F16X2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
   if (rows > 264) { set_error("split gather: halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
-  if (pieces == 3) {
+  if (pieces == SVAE_PIECES_F16X2) {
+    if (rows <= 160) hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 2, 4, 2, 160, true>), grid, dim3(512), 0, st, sa);
+    else hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 2, 4, 2, 264, true>), grid, dim3(512), 0, st, sa);
+  } else if (pieces == 3) {
     if (rows <= 160) hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 3, 4, 2, 160>), grid, dim3(512), 0, st, sa);
     else hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 3, 4, 2, 264>), grid, dim3(512), 0, st, sa);
   } else {
@@ -1561,9 +1619,12 @@ static int launch_halo(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int
 // the vector-memory path; pays once the problem has >= 2 x 256 such row tiles (batch >= 2048 for the deep layers)
 template <int BN>
 static int launch_halo256(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
-  if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
+  if (pieces != 3 && pieces != 2 && pieces != SVAE_PIECES_F16X2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
   if (rows > 528 || (pieces == 3 && rows > 320 && BN > 64)) { set_error("split gather: 256-row halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
-  if (pieces == 3) {
+  if (pieces == SVAE_PIECES_F16X2) {
+    if (rows <= 320) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 2, 4, 2, 320, true>), grid, dim3(512), 0, st, sa);
+    else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 2, 4, 2, 528, true>), grid, dim3(512), 0, st, sa);
+  } else if (pieces == 3) {
     if (rows <= 320) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 3, 4, 2, 320>), grid, dim3(512), 0, st, sa);
     else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 64, 3, 4, 2, 528>), grid, dim3(512), 0, st, sa);
   } else {
@@ -1578,18 +1639,21 @@ static int launch_halo256(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, 
 template <int BM, int BN>
 static int launch_halo_ws(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
   const dim3 block(64 * 10);
-  if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernels are built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
+  if (pieces != 3 && pieces != 2 && pieces != SVAE_PIECES_F16X2) { set_error("split gather: the halo kernels are built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
 #define SVAE_HWS(P_, R_) hipLaunchKernelGGL((gather_halo_ws_bf16s_kernel<BM, BN, P_, 4, 2, R_>), grid, block, 0, st, sa)
+#define SVAE_HWSH(R_) hipLaunchKernelGGL((gather_halo_ws_bf16s_kernel<BM, BN, 2, 4, 2, R_, 0, false, 2, true>), grid, block, 0, st, sa)
   if constexpr (BM == 128) {
-    if (rows <= 160) { if (pieces == 3) SVAE_HWS(3, 160); else SVAE_HWS(2, 160); }
-    else if (rows <= 264) { if (pieces == 3) SVAE_HWS(3, 264); else SVAE_HWS(2, 264); }
+    if (rows <= 160) { if (pieces == 3) SVAE_HWS(3, 160); else if (pieces == 2) SVAE_HWS(2, 160); else SVAE_HWSH(160); }
+    else if (rows <= 264) { if (pieces == 3) SVAE_HWS(3, 264); else if (pieces == 2) SVAE_HWS(2, 264); else SVAE_HWSH(264); }
     else { set_error("split gather: halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
   } else {
-    if (rows <= 264) { if (pieces == 3) SVAE_HWS(3, 264); else SVAE_HWS(2, 264); }
+    if (rows <= 264) { if (pieces == 3) SVAE_HWS(3, 264); else if (pieces == 2) SVAE_HWS(2, 264); else SVAE_HWSH(264); }
     else if (rows <= 320 && pieces == 2) SVAE_HWS(2, 320);
+    else if (rows <= 320 && pieces == SVAE_PIECES_F16X2) SVAE_HWSH(320);
     else { set_error("split gather: 256-row halo image of %d rows does not fit twice", rows); return SVAE_ERR_SHAPE; }
   }
 #undef SVAE_HWS
+#undef SVAE_HWSH
   return SVAE_OK;
 }
 
@@ -1598,6 +1662,15 @@ static int launch_halo_ws(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, 
 template <int BM, int BN>
 static int launch_halo_ws_pipe(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
   const dim3 block(64 * 10);
+  if (pieces == SVAE_PIECES_F16X2) {  // three weight buffers, fp16 pieces
+#define SVAE_HWPH(R_) hipLaunchKernelGGL((gather_halo_ws_bf16s_kernel<BM, BN, 2, 4, 2, R_, 0, false, 3, true>), grid, block, 0, st, sa)
+    constexpr int R0h = BM == 128 ? 160 : 264;
+    if (rows <= R0h) SVAE_HWPH(R0h);
+    else if (BM == 128 && rows <= 264) SVAE_HWPH(264);
+    else { set_error("split gather: halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
+#undef SVAE_HWPH
+    return SVAE_OK;
+  }
   if (pieces != 3 && pieces != 2) { set_error("split gather: the halo kernels are built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
   if (pieces == 3 && BN != 64) { set_error("split gather: three weight buffers with 3 pieces exist for 64-column tiles only"); return SVAE_ERR_SHAPE; }
 #define SVAE_HWP(P_, R_) hipLaunchKernelGGL((gather_halo_ws_bf16s_kernel<BM, BN, P_, 4, 2, R_, 0, false, 3>), grid, block, 0, st, sa)
@@ -1700,7 +1773,7 @@ using namespace svae;
 
 extern "C" size_t svae_conv_split_bytes(const svae_conv_desc* d) {
   if (validate(d)) return 0;
-  return (size_t)3 * (plane_f(d) + plane_d(d)) * sizeof(unsigned short);
+  return (size_t)(3 * (plane_f(d) + plane_d(d)) + 2 * plane_f(d)) * sizeof(unsigned short);
 }
 
 extern "C" int svae_conv_split_weights(const svae_conv_desc* d, const float* w, void* wsplit, void* stream) {
@@ -1709,9 +1782,9 @@ extern "C" int svae_conv_split_weights(const svae_conv_desc* d, const float* w, 
   unsigned short* out = (unsigned short*)wsplit;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(split_weights_kernel, dim3((d->c_out + 31) / 32, (d->c_in + 31) / 32, d->kernel), dim3(256), 0, st, w, out,
-                     d->kernel, d->c_in, d->c_out, 0, plane_f(d));
+                     d->kernel, d->c_in, d->c_out, 0, plane_f(d), out + 3 * plane_f(d) + 3 * plane_d(d));
   hipLaunchKernelGGL(split_weights_kernel, dim3((d->c_in + 31) / 32, (d->c_out + 31) / 32, d->kernel), dim3(256), 0, st, w,
-                     out + 3 * plane_f(d), d->kernel, d->c_in, d->c_out, 1, plane_d(d));
+                     out + 3 * plane_f(d), d->kernel, d->c_in, d->c_out, 1, plane_d(d), (unsigned short*)nullptr);
   return check_launch("split_weights");
 }
 
@@ -1738,11 +1811,12 @@ extern "C" int svae_conv_fwd_split_stats(const svae_conv_desc* d, const float* x
   if (int e = validate(d)) return e;
   SVAE_REQUIRE(x && wsplit && y, SVAE_ERR_ARG, "conv_fwd_split: null pointer");
   SVAE_REQUIRE(aligned16(x) && aligned16(wsplit) && aligned16(y), SVAE_ERR_ALIGN, "conv_fwd_split: pointers must be 16-byte aligned");
-  SVAE_REQUIRE(pieces >= 1 && pieces <= 3, SVAE_ERR_ARG, "conv_fwd_split: pieces %d not in 1..3", pieces);
+  SVAE_REQUIRE((pieces >= 1 && pieces <= 3) || pieces == SVAE_PIECES_F16X2, SVAE_ERR_ARG, "conv_fwd_split: pieces %d not in 1..3 / 22", pieces);
   SplitGatherArgs sa;
   memset(&sa, 0, sizeof(sa));
   GatherArgs& g = sa.g;
   sa.Wp = (const unsigned short*)wsplit;  // Wf planes
+  if (pieces == SVAE_PIECES_F16X2) sa.Wp += 3 * plane_f(d) + 3 * plane_d(d);  // the fp16 planes
   sa.w_piece_stride = plane_f(d);
   sa.KB = (d->c_in + 31) / 32;
   sa.rowsA = (long long)d->batch * d->l_in;

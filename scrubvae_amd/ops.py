@@ -130,18 +130,21 @@ _KIND_ID = {"fwd": 0, "dgrad": 1, "wgrad": 2}
 # is as accurate as f32.  Read when a Conv is constructed; convs below SPLIT_MIN_FLOPS stay f32.
 # The library default is "f32" (or $SVAE_PRECISION); bench.py selects "bf16x6b3".
 PRECISION = os.environ.get("SVAE_PRECISION", "f32")
-_PIECES = {"f32": 0, "bf16x6": 3, "bf16x6w3": 3, "bf16x6b3": 3, "bf16x3": 2, "bf16": 1}
+F16X2 = 22  # svae pieces code: two fp16 pieces per operand, three products (forward only; include/scrubvae_hip.h SVAE_PIECES_F16X2)
+_PIECES = {"f32": 0, "bf16x6": 3, "bf16x6w3": 3, "bf16x6b3": 3, "bf16x3": 2, "bf16": 1, "f16x3b3": F16X2}
 # "bf16x6w3": forward / data-gradient contractions with 3 pieces (6 products), WEIGHT-gradient contractions with 2
 # pieces (3 products).  A weight gradient sums >= thousands of rows; its own 2^-16-per-product rounding is invisible
 # next to the error the forward / data-gradient arithmetic already leaves on the same tensor
 # (tests/studies/precision_bf16_split.py: worst gradient error vs fp64 identical to bf16x6, 3-7x below fp32's own).
-_WGRAD_PIECES = {"bf16x6w3": 2, "bf16x6b3": 2}
+# "f16x3b3": forward with TWO FP16 pieces / 3 products (22 of 24 significand bits per operand: ~2^-22 per product, fp32-class;
+# half the matrix-core work of the 6-product bf16 split), backward as bf16x6b3 (2 bf16 pieces: gradients need bf16's exponent range).
+_WGRAD_PIECES = {"bf16x6w3": 2, "bf16x6b3": 2, "f16x3b3": 2}
 # "bf16x6b3": the whole BACKWARD pass (data- and weight-gradient contractions) with 2 pieces / 3 products, the forward
 # (outputs, every loss term, the ELBO) with 3 pieces / 6 products.  Same study, row `x6+b:x3`: worst gradient error vs
 # fp64 1.2e-3 / 4.8e-4 / 3.4e-4 / 2.2e-2 on the four fixtures against 8.3e-4 / 3.1e-3 / 3.4e-4 / 2.1e-2 for six products
 # everywhere and 5.6e-3 / 4.4e-3 / 9.2e-4 / 6.7e-2 for the reference's own fp32 arithmetic.  The data-gradient kernels read
 # the two leading planes of the 3-piece weight split (second piece truncated instead of rounded: a 2^-17 relative bias).
-_DGRAD_PIECES = {"bf16x6b3": 2}
+_DGRAD_PIECES = {"bf16x6b3": 2, "f16x3b3": 2}
 SPLIT_MIN_FLOPS = float(os.environ.get("SVAE_SPLIT_MIN_FLOPS", 2e9))
 # split gather kernels, code VBBBNNN: V = 0: 4 waves, double-buffered LDS; 1: 4 waves, one LDS buffer; 2 / 3: 8 waves
 # (BM = 128), one / two buffers; 4 / 5: wave-specialised (4 producer + 8 / 4 consumer waves), 2 tiles in flight;
@@ -286,7 +289,7 @@ class Conv:
         cands = []
         if base:
             cands += [(base, c) for c in (_SPLIT_WGRAD_CODES if kind == "wgrad" else _SPLIT_GATHER_CODES)]
-        if not base or (MIX_F32 and (base == 3 or (kind in ("wgrad", "dgrad") and self.pieces == 3))):
+        if not base or (MIX_F32 and (base in (3, F16X2) or (kind in ("wgrad", "dgrad") and self.pieces in (3, F16X2)))):
             cands += [(0, c) for c in (_WGRAD_CODES if kind == "wgrad" else _GATHER_CODES)]
         best, best_t = (base, 0), float("inf")
         for pieces, code in cands:
@@ -317,6 +320,7 @@ class Conv:
             bm, bn = C.c_int(), C.c_int()
             check(_lib.lib().svae_conv_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn)), "conv_tile")
             kp = self._kind_pieces(kind)
+            P, H = (2, "true") if kp == F16X2 else (kp, "false")
             if kp and kind == "wgrad":
                 waves = {256256: "2, 4", 256128: "4, 2", 128256: "2, 4"}.get(self.desc.tile[2] % 1000000, "2, 2")
                 names[kind] = f"wgrad_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}, {1 if self.desc.tile[2] >= 1000000 else 2}, {waves}>"
@@ -326,14 +330,14 @@ class Conv:
                                                       C.byref(rm)), "conv_split_tile")
                 v = v.value
                 if v in (8, 9):
-                    names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {kp}, 4, 2, {rm.value}>"
+                    names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {rm.value}, {H}>"
                 elif v in (10, 11, 12, 13):
-                    names[kind] = f"gather_halo_ws_bf16s_kernel<{bm.value}, {bn.value}, {kp}, 4, 2, {rm.value}, 0, false, {3 if v >= 12 else 2}>"
+                    names[kind] = f"gather_halo_ws_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {rm.value}, 0, false, {3 if v >= 12 else 2}, {H}>"
                 elif v >= 4:
                     cw = "2, 2" if v in (5, 7) else ("4, 2" if bm.value == 128 else "2, 4")
-                    names[kind] = f"gather_gemm_bf16s_ws_kernel<{bm.value}, {bn.value}, {kp}, {cw}, {2 if v < 6 else 3}, 0>"
+                    names[kind] = f"gather_gemm_bf16s_ws_kernel<{bm.value}, {bn.value}, {P}, {cw}, {2 if v < 6 else 3}, 0, {H}>"
                 else:
-                    names[kind] = f"gather_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}, {_SPLIT_VARIANT[v]}>"
+                    names[kind] = f"gather_gemm_bf16s_kernel<{bm.value}, {bn.value}, {P}, {_SPLIT_VARIANT[v]}, {H}>"
             elif kind == "wgrad":
                 names[kind] = (f"wgrad_fused_kernel<{-bm.value}, {'false' if self.desc.transposed else 'true'}>" if bm.value < 0
                                else f"wgrad_gemm_kernel<{bm.value}, {bn.value}>")

@@ -412,7 +412,7 @@ def test_gather_kernel_variants(ops, case, code):
 
 
 # ------------------------------------------------------------------ split-bf16 GEMM kernels
-_SPLIT_TOL = {3: 2e-6, 2: 6e-5, 1: 1.2e-2}  # per sqrt(K): pieces=3 is held to the fp32 kernels' bound
+_SPLIT_TOL = {3: 2e-6, 2: 6e-5, 1: 1.2e-2, 22: 8e-6}  # per sqrt(K): pieces=3 is held to the fp32 kernels' bound; 22 = two fp16 pieces (forward)
 
 
 def _split_cases():
@@ -427,6 +427,9 @@ def _split_cases():
                      10128128, 10128064, 11128128, 11128064, 12128128, 12128064, 13128128, 13128064):  # 2 pieces: the backward pass of bf16x6b3
             out.append((case, code, 2))
         out.append((case, 1128064, 1))
+        for code in (128128, 1064064, 2128064, 3128128, 4128128, 5064064, 6128064, 7064128, 8128128, 8128064, 9128128, 9128064,
+                     10128128, 11128128, 11128064, 12128128, 13128128):  # two fp16 pieces / 3 products (the forward of f16x3b3)
+            out.append((case, code, 22))
     return out
 
 
@@ -443,6 +446,8 @@ def test_split_gather_kernels(ops, case, code, pieces):
     dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
     y.backward(dy)
     cv = ops.Conv(B, L, Cin, Cout, k, s, p, 1, tr, pieces=pieces)
+    if pieces == 22:  # fp16 pieces exist for the forward only: the data-gradient of this mode runs two bf16 pieces
+        cv.dgrad_pieces = cv.wgrad_pieces = 2
     cv.__dict__["_tuned"] = {"fwd", "dgrad", "wgrad"}
     cv.desc.tile[0] = cv.desc.tile[1] = code
     ops.bump_weight_epoch()
@@ -472,7 +477,8 @@ def test_split_gather_kernels(ops, case, code, pieces):
     assert relerr(sums[0], y2.sum(0)) < 1e-5 * math.sqrt(y2.shape[0]) and relerr(sums[1], (y2 * y2).sum(0)) < 1e-5
     dxd = torch.full((B * L, cv.c_in_p), float("nan"), device="cuda")
     cv.dgrad(to_nlc(dy), wd, dxd)
-    assert relerr(from_nlc(dxd, B, L, Cin), x.grad) < tol * math.sqrt(Cout * k) + tol
+    tol_d = _SPLIT_TOL[2] if pieces == 22 else tol
+    assert relerr(from_nlc(dxd, B, L, Cin), x.grad) < tol_d * math.sqrt(Cout * k) + tol_d
     assert not torch.isnan(dxd).any()
 
 
