@@ -85,7 +85,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] measurement reported as `secondary`")
-    ap.add_argument("--timer-kinds", default="fwd,dgrad", help="GEMM kinds bracketed with HIP events (fwd,dgrad,wgrad)")
+    ap.add_argument("--timer-kinds", default="fwd,dgrad,wgrad", help="GEMM kinds bracketed with HIP events (fwd,dgrad,wgrad)")
     args = ap.parse_args()
     args.channel_list = WIDE6 if args.channels == "wide6" else [int(c) for c in args.channels.split(",")]
     wl = WORKLOADS[args.workload]

@@ -423,15 +423,16 @@ class ResVAE(nn.Module):
 
     def _allgather(self, t):
         """Concatenation of the ranks' 1-D tensors `t` in rank order (same length on every rank)."""
-        if self.world_size == 1:
-            return t
         import torch.distributed as dist
+        if self.world_size == 1 and not dist.is_initialized():
+            return t
+        n = dist.get_world_size(self.process_group)  # (the group's own size: a test may fake model.world_size)
         if t.is_cuda and dist.get_backend(self.process_group) == "gloo":  # test configuration: stage through the host
             h = t.detach().cpu()
-            out = torch.empty(self.world_size * h.numel(), dtype=h.dtype)
+            out = torch.empty(n * h.numel(), dtype=h.dtype)
             dist.all_gather_into_tensor(out, h, group=self.process_group)
             return out.to(t.device)
-        out = torch.empty(self.world_size * t.numel(), dtype=t.dtype, device=t.device)
+        out = torch.empty(n * t.numel(), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t, group=self.process_group)
         return out
 

@@ -124,6 +124,9 @@ def _rccl_worker(port, q):
                 model.bucket_min_bytes = 0
             losses, grads, stats = _run(model, dis, data, eps, ls={"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_gr": 0.0, "heading_gr": 0.0})
             out[mode] = (losses, grads.numpy())
+        # the all-gather of the adversarial shuffle's column on the RCCL backend (rank order, here one rank)
+        src = torch.arange(7, dtype=torch.float32, device="cuda") * 0.5
+        out["gather"] = model._allgather(src).cpu().numpy()
         q.put(out)
     except Exception as e:  # noqa: BLE001 -- reported to the parent instead of a queue timeout
         import traceback
@@ -142,6 +145,8 @@ def test_rccl_schedule_single_rank():
     p.join(timeout=60)
     assert "error" not in out, out.get("error")
     assert p.exitcode == 0
+    import numpy as np
+    assert np.array_equal(out["gather"], np.arange(7, dtype=np.float32) * 0.5)
     (l0, g0), (l1, g1) = out["plain"], out["ddp"]
     g0, g1 = torch.from_numpy(g0), torch.from_numpy(g1)
     # the faked world size halves every loss term and hence (local BatchNorm statistics) every gradient
