@@ -1686,6 +1686,21 @@ static int launch_halo_ws_pipe(const SplitGatherArgs& sa, dim3 grid, hipStream_t
   return SVAE_OK;
 }
 
+// V = 14 / 15: FOUR consumer waves with 128 x 64 wave tiles (one per SIMD, 256 registers each) + 2 producers on the 256 x 128 tile:
+// every operand fragment feeds 4 or 2 MFMA groups instead of 2, i.e. 25 % fewer LDS fragment bytes per MFMA -- the resource the
+// ablations show is NOT overlapped with the matrix pipe.  14: compiler-scheduled pipeline, 15: pinned (sched_barrier).  2 pieces only.
+template <bool PIPE_>
+static int launch_halo_ws_fat(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
+  const dim3 block(64 * 6);
+  if (pieces != 2 && pieces != SVAE_PIECES_F16X2) { set_error("split gather: the 128 x 64 wave tiles are built for 2 pieces"); return SVAE_ERR_SHAPE; }
+#define SVAE_HWF(R_, H_) hipLaunchKernelGGL((gather_halo_ws_bf16s_kernel<256, 128, 2, 2, 2, R_, 0, PIPE_, 3, H_>), grid, block, 0, st, sa)
+  if (rows <= 264) { if (pieces == 2) SVAE_HWF(264, false); else SVAE_HWF(264, true); }
+  else if (rows <= 320) { if (pieces == 2) SVAE_HWF(320, false); else SVAE_HWF(320, true); }
+  else { set_error("split gather: 256-row halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
+#undef SVAE_HWF
+  return SVAE_OK;
+}
+
 // tile code V*1000000 + BM*1000 + BN.  V = 0: 4 waves, double-buffered LDS;  1: 4 waves, single LDS buffer;
 // 2: 8 waves (4x2), single buffer;  3: 8 waves, double-buffered (BM = 128 only);
 // 4: wave-specialised, 4 producer + 8 consumer waves, 2 tiles in flight;  5: same with 4 consumers;
@@ -1709,9 +1724,9 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
     return check_launch("gather_halo_ws_bf16s<dbg>");
   }
 #endif
-  if (v >= 10 && v <= 13) {
-    if (t.bm != 128) { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_SHAPE; }
-    const int bmr = (v == 11 || v == 13) ? 256 : 128;
+  if (v >= 10 && v <= 15) {
+    if (t.bm != 128 || (v >= 14 && t.bn != 128)) { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_SHAPE; }
+    const int bmr = (v == 11 || v >= 13) ? 256 : 128;
     for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + bmr - 1) / bmr);
     const int nb = g.blocks_m[0] + g.blocks_m[1];
     if (nb == 0) return SVAE_OK;
@@ -1722,6 +1737,8 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
     if (v == 10) e = t.bn == 128 ? launch_halo_ws<128, 128>(sa, gridw, st, pieces, rows) : launch_halo_ws<128, 64>(sa, gridw, st, pieces, rows);
     else if (v == 11) e = t.bn == 128 ? launch_halo_ws<256, 128>(sa, gridw, st, pieces, rows) : launch_halo_ws<256, 64>(sa, gridw, st, pieces, rows);
     else if (v == 12) e = t.bn == 128 ? launch_halo_ws_pipe<128, 128>(sa, gridw, st, pieces, rows) : launch_halo_ws_pipe<128, 64>(sa, gridw, st, pieces, rows);
+    else if (v == 14) e = launch_halo_ws_fat<false>(sa, gridw, st, pieces, rows);
+    else if (v == 15) e = launch_halo_ws_fat<true>(sa, gridw, st, pieces, rows);
     else e = t.bn == 128 ? launch_halo_ws_pipe<256, 128>(sa, gridw, st, pieces, rows) : launch_halo_ws_pipe<256, 64>(sa, gridw, st, pieces, rows);
     if (e) return e;
     return check_launch("gather_halo_ws_bf16s");
@@ -1797,7 +1814,7 @@ extern "C" int svae_conv_fwd_stats_tiles(const svae_conv_desc* d) {
   build_plan(g, d, !d->transposed, d->l_out, d->l_in);
   Tile t;
   if (!decode_tile(d->tile[0], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
-  const int bm = (t.dma == 9 || t.dma == 11 || t.dma == 13) ? 256 : t.bm;
+  const int bm = (t.dma == 9 || t.dma == 11 || t.dma >= 13) ? 256 : t.bm;
   return (int)((g.M[0] + bm - 1) / bm + (g.M[1] + bm - 1) / bm);
 }
 
@@ -1838,7 +1855,7 @@ extern "C" int svae_conv_dgrad_stats_tiles(const svae_conv_desc* d, int* col_blo
   build_plan(g, d, d->transposed != 0, d->l_in, d->l_out);
   Tile t;
   if (!decode_tile(d->tile[1], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
-  const int bm = (t.dma == 9 || t.dma == 11 || t.dma == 13) ? 256 : t.bm;
+  const int bm = (t.dma == 9 || t.dma == 11 || t.dma >= 13) ? 256 : t.bm;
   if (col_blocks) *col_blocks = (g.N + t.bn - 1) / t.bn;
   return (int)((g.M[0] + bm - 1) / bm + (g.M[1] + bm - 1) / bm);
 }
@@ -1891,6 +1908,7 @@ extern "C" int svae_conv_split_tile(const svae_conv_desc* d, int kind, int* bm, 
   if (t.dma == 10 || t.dma == 12) { const int r = halo_rows(g, 128); *rmax = r <= 160 ? 160 : 264; }
   if (t.dma == 11) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 264 ? 264 : 320; }
   if (t.dma == 13) { *bm = 256; *rmax = 264; }
+  if (t.dma == 14 || t.dma == 15) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 264 ? 264 : 320; }
   return SVAE_OK;
 }
 

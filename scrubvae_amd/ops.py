@@ -155,6 +155,8 @@ _SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2
                        + (9128128, 9128064)  # 9: halo kernel on 256-row tiles (the row field of the code stays 128)
                        + (10128128, 10128064, 11128128, 11128064)  # 10 / 11: wave-specialised halo kernel, 128- / 256-row tiles
                        + (12128128, 12128064, 13128128, 13128064))  # 12 / 13: the same with three weight-tile buffers
+# (codes 14128128 / 15128128 -- four consumer waves with 128 x 64 wave tiles, compiler-scheduled / pinned pipeline -- exist and are
+#  parity-tested but measured 0-15 % slower than 11 / 13 on every benchmark layer: not tuning candidates)
 _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2, 1"}
 # 1BBBNNN: single LDS buffer; 256-edge tiles: 8 waves, half the operand bytes per FLOP through the vector-memory path
 _WGRAD_BIG = (256256, 256128, 128256)
@@ -333,6 +335,8 @@ class Conv:
                     names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {rm.value}, {H}>"
                 elif v in (10, 11, 12, 13):
                     names[kind] = f"gather_halo_ws_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {rm.value}, 0, false, {3 if v >= 12 else 2}, {H}>"
+                elif v in (14, 15):
+                    names[kind] = f"gather_halo_ws_bf16s_kernel<{bm.value}, {bn.value}, {P}, 2, 2, {rm.value}, 0, {'true' if v == 15 else 'false'}, 3, {H}>"
                 elif v >= 4:
                     cw = "2, 2" if v in (5, 7) else ("4, 2" if bm.value == 128 else "2, 4")
                     names[kind] = f"gather_gemm_bf16s_ws_kernel<{bm.value}, {bn.value}, {P}, {cw}, {2 if v < 6 else 3}, 0, {H}>"

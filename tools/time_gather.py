@@ -16,7 +16,7 @@ def timeit(fn):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / 20 * 1e-3
 for name, l_in, cin, cout, k, s, p, tr in LAYERS:
-    for kind, pieces in (("fwd", 3), ("dgrad", 2)):
+    for kind, pieces in (("fwd", int(os.environ.get("FWD_PIECES", 3))), ("dgrad", 2)):
         row = []
         for code in codes:
             cv = ops.Conv(B, l_in, cin, cout, k, s, p, 1, tr, pieces=3)
