@@ -154,7 +154,8 @@ _SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2
                        + (6128128, 6128064, 6064128) + tuple(7000000 + c for c in _TILES) + (8128128, 8128064)
                        + (9128128, 9128064)  # 9: halo kernel on 256-row tiles (the row field of the code stays 128)
                        + (10128128, 10128064, 11128128, 11128064)  # 10 / 11: wave-specialised halo kernel, 128- / 256-row tiles
-                       + (12128128, 12128064, 13128128, 13128064))  # 12 / 13: the same with three weight-tile buffers
+                       + (12128128, 12128064, 13128128, 13128064)  # 12 / 13: the same with three weight-tile buffers
+                       + (16128128, 16128064, 17128128, 17128064))  # 16 / 17: 8 consumer + 4 DMA-only loader waves, 256-row tiles, consumers staggered / not
 # (codes 14128128 / 15128128 -- four consumer waves with 128 x 64 wave tiles, compiler-scheduled / pinned pipeline -- exist and are
 #  parity-tested but measured 0-15 % slower than 11 / 13 on every benchmark layer: not tuning candidates)
 _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2, 1"}
@@ -335,6 +336,9 @@ class Conv:
                     names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {rm.value}, {H}>"
                 elif v in (10, 11, 12, 13):
                     names[kind] = f"gather_halo_ws_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {rm.value}, 0, false, {3 if v >= 12 else 2}, {H}>"
+                elif v in (16, 17):
+                    names[kind] = (f"gather_halo_ws4_bf16s_kernel<{bm.value}, {bn.value}, {rm.value}, {88 if rm.value == 264 else 64}, {H}, "
+                                   f"{'true' if v == 16 else 'false'}, 0>")
                 elif v in (14, 15):
                     names[kind] = f"gather_halo_ws_bf16s_kernel<{bm.value}, {bn.value}, {P}, 2, 2, {rm.value}, 0, {'true' if v == 15 else 'false'}, 3, {H}>"
                 elif v >= 4:
