@@ -1763,10 +1763,25 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
   auto lds_row = [](int c) { return c * WROWB + (c >> 4) * 16; };
 
   const int tid = threadIdx.x;
-  const int ti = blockIdx.x / g.ctiles;
-  const int c0 = (blockIdx.x - ti * g.ctiles) * BM;
-  const int n0 = blockIdx.y * BN;
-  const long long r_begin = (long long)blockIdx.z * g.rows_per_split;
+  // xmap: workgroups are dealt to the 8 XCDs round-robin in launch order and every XCD has an L2 of its own.  All (tap, tile) workgroups
+  // of one split read the same reduction rows of X and dY; in launch order they are spread over all 8 XCDs, so every L2 fetches every
+  // row from beyond it (measured 6-7x the operand bytes per launch).  Hand each XCD a contiguous run of the split-major workgroup
+  // list instead: the workgroups resident on an XCD then share one or two splits' rows.  Bijective for any grid (q, r split).
+  int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+  if (g.xmap) {
+    const int gxy = gridDim.x * gridDim.y, total = gxy * gridDim.z;
+    const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    bzi = w / gxy;
+    const int rem = w - bzi * gxy;
+    byi = rem / (int)gridDim.x;
+    bxi = rem - byi * (int)gridDim.x;
+  }
+  const int ti = bxi / g.ctiles;
+  const int c0 = (bxi - ti * g.ctiles) * BM;
+  const int n0 = byi * BN;
+  const long long r_begin = (long long)bzi * g.rows_per_split;
   long long r_end = r_begin + g.rows_per_split;
   if (r_end > g.R) r_end = g.R;
   const int tbx = g.bx[ti], tby = g.by[ti];
@@ -1913,7 +1928,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
     }
   }
 
-  float* out = g.out + (long long)blockIdx.z * g.slab_stride + (long long)ti * g.Kc * g.ldW;
+  float* out = g.out + (long long)bzi * g.slab_stride + (long long)ti * g.Kc * g.ldW;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = n0 + wc * WN + nt * 32 + lr;
@@ -1952,7 +1967,10 @@ static int launch_wgrad_big(const WgradArgs& g, dim3 grid, hipStream_t st, int p
 }
 
 // variant 0: double-buffered LDS; 1: single LDS buffer
-int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int pieces, int variant) {
+int launch_wgrad_split(const WgradArgs& g_in, dim3 grid, hipStream_t st, int bm, int bn, int pieces, int variant) {
+  WgradArgs g = g_in;
+  g.xmap = (variant >> 1) & 1;  // variants 2 / 3: as 0 / 1 with the XCD-aware workgroup order
+  variant &= 1;
 #define SVAE_WG_CASE(BM_, BN_)                                            \
   if (bm == BM_ && bn == BN_) {                                           \
     if (variant == 1) launch_wgrad_p<BM_, BN_, 1>(g, grid, st, pieces);   \

@@ -162,6 +162,7 @@ struct WgradArgs {
   int bx[SVAE_MAX_TAPS], by[SVAE_MAX_TAPS];
   int T, Kc, N, ldX, ldY, ldW, ctiles, bm;
   int accumulate;
+  int xmap;  // split-bf16 kernel: XCD-aware workgroup order (tile code variants 2 / 3)
 };
 
 // split-bf16 weight-gradient main kernel (gemm_bf16s.hip); same grid / slabs as wgrad_gemm_kernel

@@ -162,6 +162,8 @@ _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2
 # 1BBBNNN: single LDS buffer; 256-edge tiles: 8 waves, half the operand bytes per FLOP through the vector-memory path
 _WGRAD_BIG = (256256, 256128, 128256)
 _SPLIT_WGRAD_CODES = _TILES + tuple(1000000 + c for c in _TILES) + _WGRAD_BIG + tuple(1000000 + c for c in _WGRAD_BIG)
+# 2BBBNNN / 3BBBNNN: as 0 / 1 with the XCD-aware workgroup order (the workgroups of one reduction-row split share an XCD's L2)
+_SPLIT_WGRAD_CODES = _SPLIT_WGRAD_CODES + tuple(2000000 + c for c in _SPLIT_WGRAD_CODES)
 # BatchNorm batch statistics (forward) and first-pass backward sums from the conv GEMMs' epilogues where their kernels support it
 # (SVAE_FUSE_BN=0: the separate passes, for A/B measurements)
 FUSE_BN_STATS = os.environ.get("SVAE_FUSE_BN", "1") != "0"
@@ -326,7 +328,7 @@ class Conv:
             P, H = (2, "true") if kp == F16X2 else (kp, "false")
             if kp and kind == "wgrad":
                 waves = {256256: "2, 4", 256128: "4, 2", 128256: "2, 4"}.get(self.desc.tile[2] % 1000000, "2, 2")
-                names[kind] = f"wgrad_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}, {1 if self.desc.tile[2] >= 1000000 else 2}, {waves}>"
+                names[kind] = f"wgrad_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}, {1 if (self.desc.tile[2] // 1000000) & 1 else 2}, {waves}>"
             elif kp:
                 v, rm = C.c_int(), C.c_int()
                 check(_lib.lib().svae_conv_split_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn), C.byref(v),
