@@ -1949,6 +1949,247 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
   }
 }
 
+// ------------------------------------------------------------------------------ weight grad, all taps in one workgroup
+// wgrad_gemm_bf16s_kernel gives every tap its own workgroups: the two operand tiles of a 16-row step are loaded, converted and
+// transposed into LDS once PER TAP although all T taps multiply the same dY rows with row-shifted views of the same X rows.  Here a
+// workgroup owns a BM x BN tile of ALL taps: per 32-row stage the fixed operand F (dY of a conv) and the shifted operand S (X, with
+// its (T-1) dil halo rows) are staged once, in their NATURAL [row][channel] order -- no transposing VALU work: the k-contiguous
+// MFMA fragments are fetched with gfx950's transposing read ds_read_b64_tr_b16 -- and tap t reads S rows shifted by t dil: a plain
+// address offset in this layout.  Per loaded and converted byte the matrix cores do T times the work; the per-tap re-read of both
+// operands through the vector-memory path (the resource wgrad_gemm_bf16s_kernel is bound by) disappears.
+//   D_t[m][n] = sum_r S[(r ss + t dil - pad)][m] * F[r][n]      r = reduction row (sample b, position j < nj)
+// conv:             S = X (m = c_in),  F = dY (n = c_out), D_t = dW_t;
+// transposed conv:  S = dY (m = c_out), F = X (n = c_in),  D_t = dW_t^T (TRANS_OUT: the epilogue stores the transpose).
+// A tap that leaves its sample (0 <= j ss + t dil - pad < Ls violated) reads a zero region instead of the image: the mask is an
+// address select, no VALU work on fragments.  Requires contiguous geometry (Ls == nj ss, Lf == nj: every conv of the model except
+// the odd-length stride-2 transposed convs, which keep wgrad_gemm_bf16s_kernel), two bf16 pieces, T <= TMAX.
+// Wave tile 32 (m) x WN (n) x T taps: T x NT accumulators of 32 x 32 (T = 5, NT = 2: 160 VGPRs).
+// LDS images: 64-byte chunks (32 channels) of a row XOR-swizzled by the row so that the 4 rows x 64 bytes a half-wave's transposing
+// read touches lie on different banks.
+template <int BM, int BN, int TMAX, int SS, bool TRANS_OUT>
+__global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsArgs g) {
+  constexpr int P = 2, KS = 32, NTH = 512;
+  constexpr int WR = BM / 32, WC = 8 / WR, WN = BN / WC, NT = WN / 32;
+  static_assert(WR * WC == 8 && NT >= 1 && WN % 32 == 0, "8 waves of 32 x (32 NT)");
+  constexpr int SR = (KS - 1) * SS + (TMAX - 1) + 1;  // image rows of the shifted operand (dil = 1)
+  // image row: [piece 0: channels][piece 1: channels][pad]; the pad makes the 4 rows x 64 bytes a half-wave's transposing read
+  // touches (rows SS apart) start 64 bytes apart modulo the 256-byte bank row -- conflict-free without an XOR swizzle, so that a tap
+  // shift and the piece are IMMEDIATE offsets of the read instruction
+  constexpr int RSS = P * BM * 2 + (SS == 1 ? 64 : 32), RSF = P * BN * 2 + 64;
+  constexpr int S_ITEMS = (SR * (BM / 4) + NTH - 1) / NTH, F_ITEMS = (KS * (BN / 4) + NTH - 1) / NTH;
+  constexpr int SR_ALLOC = S_ITEMS * (NTH / (BM / 4));  // every staging item owns an image row: no conditional LDS writes
+  static_assert(F_ITEMS * (NTH / (BN / 4)) == KS, "the fixed operand's rows divide evenly over the staging items");
+  constexpr int S_IMG = SR_ALLOC * RSS, F_IMG = KS * RSF;
+  constexpr int STAGE = S_IMG + F_IMG;
+  constexpr int ZBYTES = P * BM * 2 + 64;             // zero region: what a masked read may touch at its immediate offsets
+  static_assert(2 * STAGE + ZBYTES <= 160 * 1024, "LDS budget");
+  static_assert((TMAX - 1) * RSS + BM * 2 < 65536, "tap and piece offsets are 16-bit immediates");
+  __shared__ __attribute__((aligned(64))) unsigned char smem[2 * STAGE + ZBYTES];
+  constexpr int ZOFF = 2 * STAGE;
+
+  const int tid = threadIdx.x;
+  int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+  if (g.xmap) {  // XCD-aware workgroup order: see wgrad_gemm_bf16s_kernel
+    const int gxy = gridDim.x * gridDim.y, total = gxy * gridDim.z;
+    const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    bzi = w / gxy;
+    const int rem = w - bzi * gxy;
+    byi = rem / (int)gridDim.x;
+    bxi = rem - byi * (int)gridDim.x;
+  }
+  const int c0 = bxi * BM, n0 = byi * BN;
+  const long long r_begin = (long long)bzi * g.rows_per_split;
+  long long r_end = r_begin + g.rows_per_split;
+  if (r_end > g.R) r_end = g.R;
+  const int T = g.T;
+  for (int i = tid; i < ZBYTES / 4; i += NTH) reinterpret_cast<unsigned*>(smem + ZOFF)[i] = 0u;
+
+  // ---- staging: item idx = tid + 512 i covers 4 channels (one float4) of image row idx / (channels / 4)
+  float4 sv[S_ITEMS], fv[F_ITEMS];
+  auto load_stage = [&](int kt) {
+    const long long r0 = r_begin + (long long)kt * KS;
+    const long long srow0 = r0 * g.ss - g.pad;
+#pragma unroll
+    for (int i = 0; i < S_ITEMS; ++i) {
+      const int idx = tid + NTH * i, row = idx / (BM / 4), cq = idx % (BM / 4);
+      const long long sr = srow0 + row;
+      // (select on the POINTER: a conditional load costs an exec-mask branch and a vmcnt(0) in front of the matrix work)
+      const bool ok = (row < SR) & (sr >= 0) & (sr < g.rowsS) & (c0 + cq * 4 < g.Cs);
+      sv[i] = *reinterpret_cast<const float4*>(ok ? g.S + sr * g.ldS + c0 + cq * 4 : wgrad_zero_row);
+    }
+#pragma unroll
+    for (int i = 0; i < F_ITEMS; ++i) {
+      const int idx = tid + NTH * i, row = idx / (BN / 4), cq = idx % (BN / 4);
+      const long long fr = r0 + row;
+      const bool ok = (fr < r_end) & (n0 + cq * 4 < g.Cf);
+      fv[i] = *reinterpret_cast<const float4*>(ok ? g.F + fr * g.ldF + n0 + cq * 4 : wgrad_zero_row);
+    }
+  };
+  auto store_stage = [&](int buf) {
+    unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < S_ITEMS; ++i) {
+      const int idx = tid + NTH * i, row = idx / (BM / 4), cq = idx % (BM / 4);
+      uint2 pc[P];
+      split4<P>(sv[i], pc);
+#pragma unroll
+      for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(st + row * RSS + p * (BM * 2) + cq * 8) = pc[p];
+    }
+#pragma unroll
+    for (int i = 0; i < F_ITEMS; ++i) {
+      const int idx = tid + NTH * i, row = idx / (BN / 4), cq = idx % (BN / 4);
+      uint2 pc[P];
+      split4<P>(fv[i], pc);
+#pragma unroll
+      for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(st + S_IMG + row * RSF + p * (BN * 2) + cq * 8) = pc[p];
+    }
+  };
+
+  // ---- fragment addressing (transposing reads: lane 4q+p of a 16-lane group supplies row q, channels 4p..4p+3 of a 4 x 16 block;
+  //      lane i of the group receives channel i of the 4 rows -- 4 consecutive k of its MFMA operand row)
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave / WC, wc = wave % WC;
+  const int lr = lane & 31, h = lane >> 5;
+  const int mhalf = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  // k-step ks, half j of the fragment: reduction row rr = 16 ks + 8 h + 4 j + q.  Byte offsets (in a stage) at tap 0 / piece 0 /
+  // column block 0; the tap (t RSS), the piece and the column block are immediates
+  int a_base[2][2], f_base[2][2], lbs[2][2];
+  const unsigned njm = (g.nj & (g.nj - 1)) == 0 ? (unsigned)(g.nj - 1) : 0u;  // power-of-two sample length: mask instead of modulo
+  int lpos[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = ks * 16 + 8 * h + 4 * j + q4;
+      a_base[ks][j] = rr * SS * RSS + (wr * 32 + 16 * mhalf + 4 * p4) * 2;
+      f_base[ks][j] = S_IMG + rr * RSF + (wc * WN + 16 * mhalf + 4 * p4) * 2;
+      lpos[ks][j] = (int)((r_begin + rr) % g.nj);
+    }
+
+  f32x16 acc[TMAX][NT];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][nt][r] = 0.f;
+
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
+  auto tr_read = [&](const unsigned char* p) -> uint2 {
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)p));
+  };
+  const int nk = (int)((r_end - r_begin + KS - 1) / KS);
+  auto compute = [&](int buf, auto mid) {
+    const int soff = buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 bv[NT][P];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const uint2 lo = tr_read(smem + soff + f_base[ks][0] + p * (BN * 2) + nt * 64);
+          const uint2 hi = tr_read(smem + soff + f_base[ks][1] + p * (BN * 2) + nt * 64);
+          bv[nt][p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      // position in the sample of the tap-0 source row, minus the padding: tap t is inside its sample iff 0 <= lbs + t < Ls
+#pragma unroll
+      for (int j = 0; j < 2; ++j) lbs[ks][j] = lpos[ks][j] * SS - g.pad;
+      // taps: operand fetch of tap t+1 issued in front of the multiplies of tap t
+      auto fetch_a = [&](auto t_c, uint4 (&av)[P]) {
+        constexpr int t = decltype(t_c)::value;
+        int off[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          off[j] = (unsigned)(lbs[ks][j] + t) < (unsigned)g.Ls ? soff + a_base[ks][j] + t * RSS : ZOFF;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const uint2 lo = tr_read(smem + off[0] + p * (BM * 2)), hi = tr_read(smem + off[1] + p * (BM * 2));
+          av[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      };
+      uint4 av0[P], av1[P];
+      fetch_a(std::integral_constant<int, 0>{}, av0);
+      auto tap = [&](auto t_c, uint4 (&cur)[P], uint4 (&nxt)[P]) {
+        constexpr int t = decltype(t_c)::value;
+        if (t >= T) return;
+        if constexpr (t + 1 < TMAX) { if (t + 1 < T) fetch_a(std::integral_constant<int, t + 1>{}, nxt); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_split<P>(cur, bv[nt], acc[t][nt]);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      tap(std::integral_constant<int, 0>{}, av0, av1);
+      tap(std::integral_constant<int, 1>{}, av1, av0);
+      tap(std::integral_constant<int, 2>{}, av0, av1);
+      tap(std::integral_constant<int, 3>{}, av1, av0);
+      tap(std::integral_constant<int, 4>{}, av0, av1);
+      if constexpr (TMAX > 5) tap(std::integral_constant<int, 5>{}, av1, av0);
+      if (ks == 0) mid();
+    }
+    // next stage: the reduction rows advance by KS
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned v = (unsigned)lpos[ks][j] + KS;
+        lpos[ks][j] = (int)(njm ? (v & njm) : (v % (unsigned)g.nj));
+      }
+  };
+
+  load_stage(0);
+  store_stage(0);
+  load_stage(1);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    compute(kt & 1, [&]() {
+      store_stage((kt & 1) ^ 1);
+      load_stage(kt + 2);
+    });
+    __syncthreads();
+  }
+
+  // ---- epilogue: D_t[m][n] -> out[t][.][.] of this split's slab
+  float* out = g.out + (long long)bzi * g.slab_stride;
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    if (t >= T) break;
+    float* ot = out + (long long)t * (TRANS_OUT ? g.Cf : g.Cs) * g.ldW;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + wc * WN + nt * 32 + lr;
+      if (col >= g.Cf) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = c0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < g.Cs) {
+          float* dst = TRANS_OUT ? ot + (long long)col * g.ldW + m : ot + (long long)m * g.ldW + col;
+          float v = acc[t][nt][r];
+          if (g.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+int launch_wgrad_taps(const WgradTapsArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int trans_out) {
+  const dim3 block(512);
+#define SVAE_WT(BM_, BN_, T_, S_) do {                                                                                   \
+    if (trans_out) hipLaunchKernelGGL((wgrad_taps_bf16s_kernel<BM_, BN_, T_, S_, true>), grid, block, 0, st, g);        \
+    else hipLaunchKernelGGL((wgrad_taps_bf16s_kernel<BM_, BN_, T_, S_, false>), grid, block, 0, st, g); } while (0)
+  if (g.dil != 1 || (g.ss != 1 && g.ss != 2) || g.T > 6) { set_error("wgrad taps: unsupported stride / dilation / taps"); return SVAE_ERR_SHAPE; }
+  // (a 128 x 128 tile -- 32 x 64 per wave, 160 accumulator registers for 5 taps -- spills: not instantiated)
+  if (bm == 64 && bn == 128) { if (g.ss == 1) SVAE_WT(64, 128, 6, 1); else SVAE_WT(64, 128, 6, 2); }
+  else if (bm == 128 && bn == 64) { if (g.ss == 1) SVAE_WT(128, 64, 6, 1); else SVAE_WT(128, 64, 6, 2); }
+  else { set_error("wgrad taps: tile %dx%d with %d taps unsupported", bm, bn, g.T); return SVAE_ERR_SHAPE; }
+#undef SVAE_WT
+  return check_launch("wgrad_taps_bf16s");
+}
+
 template <int BM, int BN, int NSTAGE>
 static void launch_wgrad_p(const WgradArgs& g, dim3 grid, hipStream_t st, int pieces) {
   if (pieces == 3) hipLaunchKernelGGL((wgrad_gemm_bf16s_kernel<BM, BN, 3, NSTAGE>), grid, dim3(256), 0, st, g);

@@ -165,6 +165,17 @@ struct WgradArgs {
   int xmap;  // split-bf16 kernel: XCD-aware workgroup order (tile code variants 2 / 3)
 };
 
+// all-taps split-bf16 weight-gradient kernel (gemm_bf16s.hip): grid (row tiles, column tiles, splits)
+struct WgradTapsArgs {
+  const float* S;       // shifted operand (x of a conv, dY of a transposed conv): row b Ls + j ss + t dil - pad
+  const float* F;       // fixed operand (dY of a conv, x of a transposed conv): row b nj + j
+  float* out;           // slab base [split][T][c_in][ldW] or dw itself
+  long long R, rows_per_split, slab_stride, rowsS;
+  int nj, Ls, ss, dil, pad, T;
+  int Cs, Cf, ldS, ldF, ldW;
+  int accumulate, xmap;
+};
+int launch_wgrad_taps(const WgradTapsArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int trans_out);
 // split-bf16 weight-gradient main kernel (gemm_bf16s.hip); same grid / slabs as wgrad_gemm_kernel
 int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int pieces, int variant);
 

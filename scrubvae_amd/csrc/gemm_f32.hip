@@ -1038,6 +1038,23 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
     w.nsplit = (int)((w.R + w.rps - 1) / w.rps);
     return w;
   }
+  if (d->tile[2] >= 4000000 && d->tile[2] < 8000000) {  // all-taps split-bf16 kernel (gemm_bf16s.hip): one workgroup per tile of ALL taps
+    Tile tv;
+    if (!decode_tile(d->tile[2] % 1000000, tv)) { tv.bm = 128; tv.bn = 128; }
+    w.bm = tv.bm; w.bn = tv.bn;
+    const int mdim = d->transposed ? d->c_out : d->c_in, ndim = d->transposed ? d->c_in : d->c_out;
+    w.ctiles = (mdim + w.bm - 1) / w.bm;
+    const long long tiles = (long long)w.ctiles * ((ndim + w.bn - 1) / w.bn);
+    long long want = tiles >= 256 ? 1 : 256 / tiles;  // one 8-wave workgroup per CU
+    const long long maxs = (w.R + 255) / 256;           // at least 256 reduction rows per split
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    w.rps = (w.R + want - 1) / want;
+    w.rps = ((w.rps + 31) / 32) * 32;
+    w.nsplit = (int)((w.R + w.rps - 1) / w.rps);
+    return w;
+  }
   // tile rows run over the input channels of ONE tap: 64-row tiles when c_in has no 128 multiple
   w.bm = (d->c_in % 128 == 0) ? 128 : 64;
   const int w128 = ((d->c_out + 127) / 128) * 128, w64 = ((d->c_out + 63) / 64) * 64;
@@ -1116,7 +1133,25 @@ static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float*
   else { g.out = dw; g.slab_stride = 0; g.accumulate = accumulate; }
   SVAE_REQUIRE(pieces > 0 || (wg.bm <= 128 && wg.bn <= 128), SVAE_ERR_SHAPE, "conv_wgrad: tile %dx%d exists for the split-bf16 kernel only",
                wg.bm, wg.bn);
-  if (pieces > 0) {
+  const int wvariant = d->tile[2] / 1000000;
+  if (pieces > 0 && (wvariant & 4)) {
+    const int Ls = d->transposed ? d->l_out : d->l_in;
+    SVAE_REQUIRE(pieces == 2 && d->dilation == 1 && d->kernel <= 6 && Ls == wg.nj * d->stride, SVAE_ERR_SHAPE,
+                 "conv_wgrad: the all-taps kernel needs 2 pieces, dilation 1, <= 6 taps and l == nj * stride");
+    WgradTapsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.S = d->transposed ? dy : x; a.F = d->transposed ? x : dy;
+    a.R = wg.R; a.rows_per_split = wg.rps; a.nj = wg.nj;
+    a.Ls = Ls; a.ss = d->stride; a.dil = d->dilation; a.pad = d->padding; a.T = d->kernel;
+    a.rowsS = (long long)d->batch * Ls;
+    a.Cs = d->transposed ? d->c_out : d->c_in; a.Cf = d->transposed ? d->c_in : d->c_out;
+    a.ldS = d->transposed ? d->ld_out : d->ld_in; a.ldF = d->transposed ? d->ld_in : d->ld_out; a.ldW = d->c_out;
+    a.xmap = (wvariant >> 1) & 1;
+    if (nsplit > 1) { a.out = slab; a.slab_stride = wsize; a.accumulate = 0; }
+    else { a.out = dw; a.slab_stride = 0; a.accumulate = accumulate; }
+    dim3 grid(wg.ctiles, (a.Cf + wg.bn - 1) / wg.bn, nsplit);
+    if (int e = launch_wgrad_taps(a, grid, st, wg.bm, wg.bn, d->transposed ? 1 : 0)) return e;
+  } else if (pieces > 0) {
     dim3 grid(d->kernel * g.ctiles, (d->c_out + wg.bn - 1) / wg.bn, nsplit);
     if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces, d->tile[2] / 1000000)) return e;
   } else if (wg.fused) {

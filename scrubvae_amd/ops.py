@@ -164,6 +164,8 @@ _WGRAD_BIG = (256256, 256128, 128256)
 _SPLIT_WGRAD_CODES = _TILES + tuple(1000000 + c for c in _TILES) + _WGRAD_BIG + tuple(1000000 + c for c in _WGRAD_BIG)
 # 2BBBNNN / 3BBBNNN: as 0 / 1 with the XCD-aware workgroup order (the workgroups of one reduction-row split share an XCD's L2)
 _SPLIT_WGRAD_CODES = _SPLIT_WGRAD_CODES + tuple(2000000 + c for c in _SPLIT_WGRAD_CODES)
+# 4BBBNNN / 6BBBNNN: all taps of a tile in one workgroup (wgrad_taps_bf16s_kernel), launch order / XCD-aware order
+_SPLIT_WGRAD_CODES = _SPLIT_WGRAD_CODES + (4064128, 4128064, 6064128, 6128064)
 # BatchNorm batch statistics (forward) and first-pass backward sums from the conv GEMMs' epilogues where their kernels support it
 # (SVAE_FUSE_BN=0: the separate passes, for A/B measurements)
 FUSE_BN_STATS = os.environ.get("SVAE_FUSE_BN", "1") != "0"
@@ -326,7 +328,10 @@ class Conv:
             check(_lib.lib().svae_conv_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn)), "conv_tile")
             kp = self._kind_pieces(kind)
             P, H = (2, "true") if kp == F16X2 else (kp, "false")
-            if kp and kind == "wgrad":
+            if kp and kind == "wgrad" and (self.desc.tile[2] // 1000000) & 4:
+                names[kind] = (f"wgrad_taps_bf16s_kernel<{bm.value}, {bn.value}, 6, "
+                               f"{self.desc.stride}, {'true' if self.desc.transposed else 'false'}>")
+            elif kp and kind == "wgrad":
                 waves = {256256: "2, 4", 256128: "4, 2", 128256: "2, 4"}.get(self.desc.tile[2] % 1000000, "2, 2")
                 names[kind] = f"wgrad_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}, {1 if (self.desc.tile[2] // 1000000) & 1 else 2}, {waves}>"
             elif kp:
@@ -364,7 +369,7 @@ class Conv:
         """Workspace for the current tile; before tuning: the maximum over all candidate tiles."""
         if "wgrad" not in self.__dict__.get("_tuned", ()) and AUTOTUNE and self.flops >= AUTOTUNE_MIN_FLOPS:
             keep, need = self.desc.tile[2], 0
-            for code in _WGRAD_CODES:
+            for code in (_SPLIT_WGRAD_CODES if self._base_pieces("wgrad") else _WGRAD_CODES):
                 self.desc.tile[2] = code
                 need = max(need, int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc))))
             self.desc.tile[2] = keep
@@ -470,7 +475,7 @@ class Conv:
             sdb = torch.empty(self.c_out_p, device=x.device)
             self.desc.tile[2] = 0
             need = 0
-            for code in _WGRAD_CODES:  # scratch workspace large enough for every candidate
+            for code in (_SPLIT_WGRAD_CODES if self._base_pieces("wgrad") else _WGRAD_CODES):  # scratch workspace large enough for every candidate
                 self.desc.tile[2] = code
                 need = max(need, int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc))))
             self.desc.tile[2] = 0

@@ -488,7 +488,8 @@ def test_split_gather_kernels(ops, case, code, pieces):
 @pytest.mark.parametrize("code,pieces", [(128128, 3), (64128, 3), (128064, 3), (64064, 3), (0, 3), (64064, 2), (128064, 1),
                                          (256256, 2), (1256256, 2), (256128, 2), (1128256, 2), (1256256, 3), (1256128, 3),
                                          (1128128, 3), (1064128, 3), (1128064, 3), (1064064, 3),
-                                         (2256256, 2), (3256128, 2), (2128128, 2), (3064064, 2), (2064128, 3)])
+                                         (2256256, 2), (3256128, 2), (2128128, 2), (3064064, 2), (2064128, 3),
+                                         (4064128, 2), (6064128, 2), (4128064, 2), (6128064, 2)])
 def test_split_wgrad_kernels(ops, case, code, pieces):
     B, L, Cin, Cout, k, s, p, tr = case
     g = torch.Generator().manual_seed(13 + sum(case[:7]))
@@ -505,7 +506,12 @@ def test_split_wgrad_kernels(ops, case, code, pieces):
     ws = torch.empty(cv.wgrad_workspace_bytes() // 4 + 4, device="cuda")
     dwd = torch.full(cv.weight_shape, float("nan"), device="cuda")
     dbd = torch.full((cv.c_out_p,), float("nan"), device="cuda")
-    cv.wgrad(xd, dyd, dwd, dbd, ws)
+    try:
+        cv.wgrad(xd, dyd, dwd, dbd, ws)
+    except RuntimeError as e:
+        if code >= 4000000 and ("all-taps kernel" in str(e) or "wgrad taps" in str(e)):
+            pytest.skip("geometry outside the all-taps kernel (odd-length strided transposed conv, > 6 taps): the tuner skips it the same way")
+        raise
     tol = _SPLIT_TOL[pieces]
     bound = tol * math.sqrt(B * y.shape[-1]) + tol
     assert relerr(ops.conv_weight_from_tio(dwd.cpu(), Cin, Cout, tr), w.grad) < bound

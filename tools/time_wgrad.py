@@ -28,7 +28,7 @@ for name, l_in, cin, cout, k, s, p, tr in LAYERS:
         db = torch.empty(cv.c_out_p, device="cuda")
         try:
             ws = torch.empty(cv.wgrad_workspace_bytes() // 4 + 4, device="cuda")
-            t = timeit(lambda: cv.wgrad(x, dy, dw, db, ws))
+            t = timeit(lambda: cv.wgrad(x, dy, dw, None, ws))
             row.append(f"{code}: {t*1e6:6.1f} us {cv.flops/t/1e12:6.1f} TF")
         except RuntimeError as e:
             row.append(f"{code}: n/a")
