@@ -100,39 +100,42 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, double count,
 }
 
 // reduce the chunk partials AND finalize in one launch (single-rank path: no all-reduce between)
-// 256 threads = 32 channels x 8 chunk-lanes: lane s of a channel sums chunks s, s+8, ... in fp64, the eight
-// lane sums are combined in lane order (deterministic); adjacent threads read adjacent channels.
-constexpr int FIN_SUB = 32, FIN_CH = 8;
+// 256 threads = cpb channels x (256 / cpb) chunk-lanes: lane s of a channel sums chunks s, s + nsub, ... in fp64, the lane sums are
+// combined in lane order (deterministic); adjacent threads read adjacent channels.  cpb shrinks with the channel count so that
+// the shallow layers -- few channels, thousands of row-tile partials -- still spread over >= 64 workgroups (a block per 8
+// channels left 8 workgroups walking 2,048 partials each: 39 us per BatchNorm on the critical path).
+constexpr int FIN_THREADS = 256;
+static inline int fin_cpb(int C) { return C >= 512 ? 8 : (C >= 256 ? 4 : (C >= 128 ? 2 : 1)); }
 
-__device__ __forceinline__ bool chunk_sums(const float* __restrict__ part, int chunks, int C, int c, int sub, double& s0, double& s1,
-                                           double (*red)[FIN_SUB][FIN_CH]) {
+__device__ __forceinline__ bool chunk_sums(const float* __restrict__ part, int chunks, int C, int cpb, double& s0, double& s1, int& c,
+                                           double (*red)[FIN_THREADS]) {
+  const int nsub = FIN_THREADS / cpb;
+  const int sub = threadIdx.x / cpb, cl = threadIdx.x % cpb;
+  c = blockIdx.x * cpb + cl;
   double a0 = 0.0, a1 = 0.0;
   if (c < C)
-    for (int ch = sub; ch < chunks; ch += FIN_SUB) {
+    for (int ch = sub; ch < chunks; ch += nsub) {
       a0 += (double)part[((long long)ch * 2) * C + c];
       a1 += (double)part[((long long)ch * 2 + 1) * C + c];
     }
-  const int cl = threadIdx.x % FIN_CH;
-  red[0][sub][cl] = a0;
-  red[1][sub][cl] = a1;
+  red[0][threadIdx.x] = a0;
+  red[1][threadIdx.x] = a1;
   __syncthreads();
   if (sub != 0 || c >= C) return false;
   s0 = 0.0; s1 = 0.0;
-#pragma unroll
-  for (int i = 0; i < FIN_SUB; ++i) { s0 += red[0][i][cl]; s1 += red[1][i][cl]; }
+  for (int i = 0; i < nsub; ++i) { s0 += red[0][i * cpb + cl]; s1 += red[1][i * cpb + cl]; }
   return true;
 }
 
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, double count, int C,
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int chunks, double count, int C, int cpb,
                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                          float* running_mean, float* running_var, long long* num_batches_tracked, float* mean_o,
                                          float* rstd_o, float* scale, float* shift) {
-  __shared__ double red[2][FIN_SUB][FIN_CH];
-  const int sub = threadIdx.x / FIN_CH;
-  const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+  __shared__ double red[2][FIN_THREADS];
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
   double s0, s1;
-  if (!chunk_sums(part, chunks, C, c, sub, s0, s1, red)) return;
+  int c;
+  if (!chunk_sums(part, chunks, C, cpb, s0, s1, c, red)) return;
   const double mean = s0 / count;
   double var = s1 / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -150,13 +153,11 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
 }
 
 // backward: reduce the chunk partials to sums[2][C] and emit the parameter gradients
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ sums,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ part, int chunks, int C, int cpb, float* __restrict__ sums,
                                      float* dgamma, float* dbeta, float* dalpha, const float* __restrict__ dalpha_part, int n_parts,
                                      int accumulate) {
-  __shared__ double red[2][FIN_SUB][FIN_CH];
+  __shared__ double red[2][FIN_THREADS];
   __shared__ double dsum[256];
-  const int sub = threadIdx.x / FIN_CH;
-  const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
   if (blockIdx.x == 0 && dalpha != nullptr) {  // PReLU slope: all partials, strided fp64 sums + fixed-order tree
     double acc = 0.0;
     for (int i = threadIdx.x; i < n_parts; i += 256) acc += (double)dalpha_part[i];
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (threadIdx.x == 0) dalpha[0] = (accumulate ? dalpha[0] : 0.f) + (float)dsum[0];
   }
   double s0, s1;
-  if (!chunk_sums(part, chunks, C, c, sub, s0, s1, red)) return;
+  int c;
+  if (!chunk_sums(part, chunks, C, cpb, s0, s1, c, red)) return;
   sums[c] = (float)s0;
   sums[C + c] = (float)s1;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s0;
@@ -896,7 +898,8 @@ extern "C" int svae_bn_stats_finalize(const float* part, int n_chunks, double co
                                       void* stream) {
   SVAE_REQUIRE(part && gamma && beta && mean && rstd && scale && shift && count > 0 && n_chunks > 0, SVAE_ERR_ARG,
                "bn_stats_finalize: bad args");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, ST(stream), part, n_chunks, count, C, gamma,
+  const int cpb = fin_cpb(C);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + cpb - 1) / cpb), dim3(256), 0, ST(stream), part, n_chunks, count, C, cpb, gamma,
                      beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale, shift);
   return check_launch("bn_stats_finalize");
 }
@@ -904,7 +907,8 @@ extern "C" int svae_bn_stats_finalize(const float* part, int n_chunks, double co
 extern "C" int svae_bn_bwd_reduce(const float* part, int n_chunks, int C, float* sums, float* dgamma, float* dbeta,
                                   float* dalpha, const float* dalpha_part, int n_parts, int accumulate, void* stream) {
   SVAE_REQUIRE(part && sums && n_chunks > 0 && (!dalpha || dalpha_part), SVAE_ERR_ARG, "bn_bwd_reduce: bad args");
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, ST(stream), part, n_chunks, C, sums, dgamma, dbeta,
+  const int cpb = fin_cpb(C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + cpb - 1) / cpb), dim3(256), 0, ST(stream), part, n_chunks, C, cpb, sums, dgamma, dbeta,
                      dalpha, dalpha_part, n_parts, accumulate);
   return check_launch("bn_bwd_reduce");
 }
