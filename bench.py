@@ -316,6 +316,7 @@ def run_workload(args, full, B, rank, world, roofline=True):
         dt = float(tt)
     res = {"value": round(B * world * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 3),
            "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3), "final_total_loss": float(bl["total"].detach()),
+           "side_streams": bool(model._ov) and not args.serial_streams,
            "workload": workload_name(args, full, B), "batch_per_gpu": B}
     if timer is not None:
         summ = timer.summary()
@@ -395,7 +396,7 @@ def main():
                        "joints": args.joints, "launch": "hipGraph replay" if args.graph else "eager launches",
                        "inputs": ("copied from pinned host memory for every step, one batch ahead on a copy stream (PCIe-inclusive)"
                                   if args.h2d else "resident in HBM"),
-                       "streams": "serialised" if args.serial_streams else "3 HIP streams (weight gradients / skip branches overlap the main chain)",
+                       "streams": "3 HIP streams (weight gradients / skip branches overlap the main chain)" if head["side_streams"] else "one stream (serialised: chosen below 32768 batch x window rows, or --serial-streams)",
                        "precision": precision_text(args.precision),
                        "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("+syncbn" if args.sync_bn else "+localbn")),

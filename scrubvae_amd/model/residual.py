@@ -182,8 +182,12 @@ class ResVAE(nn.Module):
         # only valid after get_batch_loss (which runs the fused tail once).  Off by default.
         self.defer_tail = False
         self._tail_done = True
-        # weight-gradient GEMMs on a second stream, concurrent with the data-gradient chain
-        self.overlap_wgrad = True
+        # weight-gradient GEMMs / skip branches on side streams, concurrent with the main chain.  None = decide per pass from the
+        # batch: with fewer than `overlap_min_rows` (batch x window) rows the kernels are shorter than the cross-stream hand-overs
+        # cost (measured on configs[1]: B=32 8.3k -> 14k, B=256 51k -> 77k windows/s WITHOUT the side streams; B=1024 194k -> 212k with)
+        self.overlap_wgrad = None
+        self.overlap_min_rows = 32768
+        self._ov = True
         self._sides, self._side_dirty, self._events, self._event_i = [], set(), [], 0
         self._ws = {}
         self._convs = {}
@@ -365,7 +369,7 @@ class ResVAE(nn.Module):
     def _fork(self, fn, k=1):
         """Run fn() on side stream k, ordered after everything queued on the main stream so far.
         Stream 0 carries the weight gradients, stream 1 the skip branches."""
-        if not self.overlap_wgrad:
+        if not self._ov:
             return fn()
         main = self._main_stream()
         side = self._side_stream(k)
@@ -454,7 +458,7 @@ class ResVAE(nn.Module):
         if hi <= lo:
             return None
         t = self.flat_grads[lo:hi]
-        if dist.get_backend(self.process_group) == "gloo" or not self.overlap_wgrad:
+        if dist.get_backend(self.process_group) == "gloo" or not self._ov:
             self._join_side()
             return self._allreduce(t, async_op=True)
         comm = self._side_stream(2)
@@ -716,6 +720,7 @@ class ResVAE(nn.Module):
     def encode(self, data):
         """ResVAE.encode (residual.py:438-459): returns {"mu": [B,z], "L": [B,z,z]}."""
         self._new_pass()
+        self._ov = (data["x6d"].shape[0] * self.window >= self.overlap_min_rows) if self.overlap_wgrad is None else bool(self.overlap_wgrad)
         B, flat, h = self._encode_trunk(data)
         mu, sigma, zc, klp = self._heads(B, h, None)
         self._state = dict(B=B, flat=flat, h=h, eps=None)
