@@ -2003,14 +2003,16 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
   const long long r_begin = (long long)bzi * g.rows_per_split;
   long long r_end = r_begin + g.rows_per_split;
   if (r_end > g.R) r_end = g.R;
-  const int T = g.T;
+  constexpr int T = TMAX;  // (a run-time tap count puts the multiplies behind branches and hipcc then keeps every accumulator twice)
   for (int i = tid; i < ZBYTES / 4; i += NTH) reinterpret_cast<unsigned*>(smem + ZOFF)[i] = 0u;
 
   // ---- staging: item idx = tid + 512 i covers 4 channels (one float4) of image row idx / (channels / 4)
+  // The two operands are staged in turn (S: requested in front of a stage's first k-step, written behind it; F: requested there,
+  // written behind the second k-step), so that only one of them occupies registers at a time: with 5 taps x 2 column blocks the
+  // accumulators alone take 160 of the 256 registers.
   float4 sv[S_ITEMS], fv[F_ITEMS];
-  auto load_stage = [&](int kt) {
-    const long long r0 = r_begin + (long long)kt * KS;
-    const long long srow0 = r0 * g.ss - g.pad;
+  auto load_s = [&](int kt) {
+    const long long srow0 = (r_begin + (long long)kt * KS) * g.ss - g.pad;
 #pragma unroll
     for (int i = 0; i < S_ITEMS; ++i) {
       const int idx = tid + NTH * i, row = idx / (BM / 4), cq = idx % (BM / 4);
@@ -2019,6 +2021,9 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
       const bool ok = (row < SR) & (sr >= 0) & (sr < g.rowsS) & (c0 + cq * 4 < g.Cs);
       sv[i] = *reinterpret_cast<const float4*>(ok ? g.S + sr * g.ldS + c0 + cq * 4 : wgrad_zero_row);
     }
+  };
+  auto load_f = [&](int kt) {
+    const long long r0 = r_begin + (long long)kt * KS;
 #pragma unroll
     for (int i = 0; i < F_ITEMS; ++i) {
       const int idx = tid + NTH * i, row = idx / (BN / 4), cq = idx % (BN / 4);
@@ -2027,7 +2032,7 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
       fv[i] = *reinterpret_cast<const float4*>(ok ? g.F + fr * g.ldF + n0 + cq * 4 : wgrad_zero_row);
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_s = [&](int buf) {
     unsigned char* st = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < S_ITEMS; ++i) {
@@ -2037,6 +2042,9 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
 #pragma unroll
       for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(st + row * RSS + p * (BM * 2) + cq * 8) = pc[p];
     }
+  };
+  auto store_f = [&](int buf) {
+    unsigned char* st = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < F_ITEMS; ++i) {
       const int idx = tid + NTH * i, row = idx / (BN / 4), cq = idx % (BN / 4);
@@ -2054,19 +2062,11 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
   const int lr = lane & 31, h = lane >> 5;
   const int mhalf = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
   // k-step ks, half j of the fragment: reduction row rr = 16 ks + 8 h + 4 j + q.  Byte offsets (in a stage) at tap 0 / piece 0 /
-  // column block 0; the tap (t RSS), the piece and the column block are immediates
-  int a_base[2][2], f_base[2][2], lbs[2][2];
+  // column block 0 (the tap (t RSS), the piece and the column block are immediates) are rebuilt from rr per k-step
+  const int rr0 = 8 * h + q4;
+  const int a_lane = (wr * 32 + 16 * mhalf + 4 * p4) * 2, f_lane = S_IMG + (wc * WN + 16 * mhalf + 4 * p4) * 2;
   const unsigned njm = (g.nj & (g.nj - 1)) == 0 ? (unsigned)(g.nj - 1) : 0u;  // power-of-two sample length: mask instead of modulo
-  int lpos[2][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int rr = ks * 16 + 8 * h + 4 * j + q4;
-      a_base[ks][j] = rr * SS * RSS + (wr * 32 + 16 * mhalf + 4 * p4) * 2;
-      f_base[ks][j] = S_IMG + rr * RSF + (wc * WN + 16 * mhalf + 4 * p4) * 2;
-      lpos[ks][j] = (int)((r_begin + rr) % g.nj);
-    }
+  int lpos0 = (int)((r_begin + rr0) % g.nj);  // position in its sample of reduction row rr0 of the current stage
 
   f32x16 acc[TMAX][NT];
 #pragma unroll
@@ -2082,29 +2082,34 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
     return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)p));
   };
   const int nk = (int)((r_end - r_begin + KS - 1) / KS);
-  auto compute = [&](int buf, auto mid) {
+  auto wrap = [&](int v) { return (int)(njm ? ((unsigned)v & njm) : ((unsigned)v % (unsigned)g.nj)); };
+  auto compute = [&](int buf, auto mid, auto tail) {
     const int soff = buf * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      int a_base[2], f_base[2], lbs[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rr = ks * 16 + 4 * j + rr0;
+        a_base[j] = soff + rr * (SS * RSS) + a_lane;
+        f_base[j] = soff + rr * RSF + f_lane;
+        // position in the sample of the tap-0 source row, minus the padding: tap t is inside its sample iff 0 <= lbs + t < Ls
+        lbs[j] = wrap(lpos0 + ks * 16 + 4 * j) * SS - g.pad;
+      }
       uint4 bv[NT][P];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          const uint2 lo = tr_read(smem + soff + f_base[ks][0] + p * (BN * 2) + nt * 64);
-          const uint2 hi = tr_read(smem + soff + f_base[ks][1] + p * (BN * 2) + nt * 64);
+          const uint2 lo = tr_read(smem + f_base[0] + p * (BN * 2) + nt * 64), hi = tr_read(smem + f_base[1] + p * (BN * 2) + nt * 64);
           bv[nt][p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
-      // position in the sample of the tap-0 source row, minus the padding: tap t is inside its sample iff 0 <= lbs + t < Ls
-#pragma unroll
-      for (int j = 0; j < 2; ++j) lbs[ks][j] = lpos[ks][j] * SS - g.pad;
       // taps: operand fetch of tap t+1 issued in front of the multiplies of tap t
       auto fetch_a = [&](auto t_c, uint4 (&av)[P]) {
         constexpr int t = decltype(t_c)::value;
         int off[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          off[j] = (unsigned)(lbs[ks][j] + t) < (unsigned)g.Ls ? soff + a_base[ks][j] + t * RSS : ZOFF;
+        for (int j = 0; j < 2; ++j) off[j] = (unsigned)(lbs[j] + t) < (unsigned)g.Ls ? a_base[j] + t * RSS : ZOFF;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           const uint2 lo = tr_read(smem + off[0] + p * (BM * 2)), hi = tr_read(smem + off[1] + p * (BM * 2));
@@ -2115,8 +2120,7 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
       fetch_a(std::integral_constant<int, 0>{}, av0);
       auto tap = [&](auto t_c, uint4 (&cur)[P], uint4 (&nxt)[P]) {
         constexpr int t = decltype(t_c)::value;
-        if (t >= T) return;
-        if constexpr (t + 1 < TMAX) { if (t + 1 < T) fetch_a(std::integral_constant<int, t + 1>{}, nxt); }
+        if constexpr (t + 1 < TMAX) fetch_a(std::integral_constant<int, t + 1>{}, nxt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_split<P>(cur, bv[nt], acc[t][nt]);
@@ -2128,27 +2132,23 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
       tap(std::integral_constant<int, 3>{}, av1, av0);
       tap(std::integral_constant<int, 4>{}, av0, av1);
       if constexpr (TMAX > 5) tap(std::integral_constant<int, 5>{}, av1, av0);
-      if (ks == 0) mid();
+      if (ks == 0) mid(); else tail();
     }
-    // next stage: the reduction rows advance by KS
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const unsigned v = (unsigned)lpos[ks][j] + KS;
-        lpos[ks][j] = (int)(njm ? (v & njm) : (v % (unsigned)g.nj));
-      }
+    lpos0 = wrap(lpos0 + KS);  // next stage: the reduction rows advance by KS
   };
 
-  load_stage(0);
-  store_stage(0);
-  load_stage(1);
+  // stage kt+1 is staged while stage kt is multiplied: S requested before, written between the two k-steps; F requested there,
+  // written after the second
+  load_s(0);
+  load_f(0);
+  store_s(0);
+  store_f(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    compute(kt & 1, [&]() {
-      store_stage((kt & 1) ^ 1);
-      load_stage(kt + 2);
-    });
+    load_s(kt + 1);
+    compute(kt & 1,
+            [&]() { store_s((kt & 1) ^ 1); load_f(kt + 1); },
+            [&]() { store_f((kt & 1) ^ 1); });
     __syncthreads();
   }
 
@@ -2156,20 +2156,34 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
   float* out = g.out + (long long)bzi * g.slab_stride;
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) {
-    if (t >= T) break;
     float* ot = out + (long long)t * (TRANS_OUT ? g.Cf : g.Cs) * g.ldW;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int col = n0 + wc * WN + nt * 32 + lr;
       if (col >= g.Cf) continue;
+      if constexpr (TRANS_OUT) {
+        // D_t is dW_t^T: a lane's 4 consecutive accumulator rows are 4 consecutive output channels of input channel `col` -- one
+        // 16-byte store each (c_out is a multiple of 16: rows of dW are 64-byte aligned)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = c0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < g.Cs) {
-          float* dst = TRANS_OUT ? ot + (long long)col * g.ldW + m : ot + (long long)m * g.ldW + col;
-          float v = acc[t][nt][r];
-          if (g.accumulate) v += *dst;
-          *dst = v;
+        for (int rq = 0; rq < 4; ++rq) {
+          const int m = c0 + wr * 32 + 8 * rq + 4 * h;
+          if (m < g.Cs) {
+            float4* dst = reinterpret_cast<float4*>(ot + (long long)col * g.ldW + m);
+            float4 v = make_float4(acc[t][nt][4 * rq], acc[t][nt][4 * rq + 1], acc[t][nt][4 * rq + 2], acc[t][nt][4 * rq + 3]);
+            if (g.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *dst = v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = c0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < g.Cs) {
+            float* dst = ot + (long long)m * g.ldW + col;
+            float v = acc[t][nt][r];
+            if (g.accumulate) v += *dst;
+            *dst = v;
+          }
         }
       }
     }
@@ -2181,11 +2195,13 @@ int launch_wgrad_taps(const WgradTapsArgs& g, dim3 grid, hipStream_t st, int bm,
 #define SVAE_WT(BM_, BN_, T_, S_) do {                                                                                   \
     if (trans_out) hipLaunchKernelGGL((wgrad_taps_bf16s_kernel<BM_, BN_, T_, S_, true>), grid, block, 0, st, g);        \
     else hipLaunchKernelGGL((wgrad_taps_bf16s_kernel<BM_, BN_, T_, S_, false>), grid, block, 0, st, g); } while (0)
-  if (g.dil != 1 || (g.ss != 1 && g.ss != 2) || g.T > 6) { set_error("wgrad taps: unsupported stride / dilation / taps"); return SVAE_ERR_SHAPE; }
-  // (a 128 x 128 tile -- 32 x 64 per wave, 160 accumulator registers for 5 taps -- spills: not instantiated)
-  if (bm == 64 && bn == 128) { if (g.ss == 1) SVAE_WT(64, 128, 6, 1); else SVAE_WT(64, 128, 6, 2); }
-  else if (bm == 128 && bn == 64) { if (g.ss == 1) SVAE_WT(128, 64, 6, 1); else SVAE_WT(128, 64, 6, 2); }
+  if (g.dil != 1 || (g.ss != 1 && g.ss != 2) || (g.T != 5 && g.T != 6)) { set_error("wgrad taps: built for 5 or 6 taps, stride 1 or 2, dilation 1"); return SVAE_ERR_SHAPE; }
+#define SVAE_WTT(BM_, BN_, S_) do { if (g.T == 5) SVAE_WT(BM_, BN_, 5, S_); else SVAE_WT(BM_, BN_, 6, S_); } while (0)
+  if (bm == 128 && bn == 128 && g.T == 5) { if (g.ss == 1) SVAE_WT(128, 128, 5, 1); else SVAE_WT(128, 128, 5, 2); }
+  else if (bm == 64 && bn == 128) { if (g.ss == 1) SVAE_WTT(64, 128, 1); else SVAE_WTT(64, 128, 2); }
+  else if (bm == 128 && bn == 64) { if (g.ss == 1) SVAE_WTT(128, 64, 1); else SVAE_WTT(128, 64, 2); }
   else { set_error("wgrad taps: tile %dx%d with %d taps unsupported", bm, bn, g.T); return SVAE_ERR_SHAPE; }
+#undef SVAE_WTT
 #undef SVAE_WT
   return check_launch("wgrad_taps_bf16s");
 }

@@ -1136,8 +1136,8 @@ static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float*
   const int wvariant = d->tile[2] / 1000000;
   if (pieces > 0 && (wvariant & 4)) {
     const int Ls = d->transposed ? d->l_out : d->l_in;
-    SVAE_REQUIRE(pieces == 2 && d->dilation == 1 && d->kernel <= 6 && Ls == wg.nj * d->stride, SVAE_ERR_SHAPE,
-                 "conv_wgrad: the all-taps kernel needs 2 pieces, dilation 1, <= 6 taps and l == nj * stride");
+    SVAE_REQUIRE(pieces == 2 && d->dilation == 1 && (d->kernel == 5 || d->kernel == 6) && Ls == wg.nj * d->stride, SVAE_ERR_SHAPE,
+                 "conv_wgrad: the all-taps kernel needs 2 pieces, dilation 1, 5 or 6 taps and l == nj * stride");
     WgradTapsArgs a;
     memset(&a, 0, sizeof(a));
     a.S = d->transposed ? dy : x; a.F = d->transposed ? x : dy;

@@ -7,14 +7,30 @@ B = int(os.environ.get("B", 1024))
 LAYERS = [("enc3.c3", 4, 512, 1024, 5, 1, 2, False), ("dec0.sk", 8, 1024, 512, 6, 1, 2, False), ("dec0.t1", 4, 1024, 512, 5, 1, 2, True),
           ("enc2.c3", 8, 256, 512, 5, 1, 2, False), ("dec1.sk", 14, 512, 256, 6, 1, 2, False), ("enc1.c3", 16, 128, 256, 5, 1, 2, False)]
 codes = [int(c) for c in sys.argv[1:]] or [8128128, 9128128]
+COLD = os.environ.get("COLD", "0") != "0"
+_flush = None
 def timeit(fn):
+    """Mean launch time.  COLD=1: every timed launch follows a 1 GiB write that evicts the operands from L2 and the Infinity
+    Cache -- the state a layer's operands are in when its kernel runs inside a training step (repeated launches on the same
+    tensors otherwise read them from the 256 MiB Infinity Cache and flatter kernels with a short prefetch distance)."""
+    global _flush
     for _ in range(3): fn()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(20): fn()
-    e.record(); torch.cuda.synchronize()
-    return s.elapsed_time(e) / 20 * 1e-3
+    if not COLD:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20): fn()
+        e.record(); torch.cuda.synchronize()
+        return s.elapsed_time(e) / 20 * 1e-3
+    if _flush is None:
+        _flush = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    tot = 0.0
+    for _ in range(8):
+        _flush.add_(1.0)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record(); torch.cuda.synchronize()
+        tot += s.elapsed_time(e)
+    return tot / 8 * 1e-3
 for name, l_in, cin, cout, k, s, p, tr in LAYERS:
     for kind, pieces in (("fwd", int(os.environ.get("FWD_PIECES", 3))), ("dgrad", 2)):
         row = []
