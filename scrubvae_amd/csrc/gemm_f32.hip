@@ -1038,7 +1038,7 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
     w.nsplit = (int)((w.R + w.rps - 1) / w.rps);
     return w;
   }
-  if (d->tile[2] >= 4000000 && d->tile[2] < 8000000) {  // all-taps split-bf16 kernel (gemm_bf16s.hip): one workgroup per tile of ALL taps
+  if ((d->tile[2] / 1000000) & 4) {  // all-taps split-bf16 kernel (gemm_bf16s.hip): one workgroup per tile of ALL taps
     Tile tv;
     if (!decode_tile(d->tile[2] % 1000000, tv)) { tv.bm = 128; tv.bn = 128; }
     w.bm = tv.bm; w.bn = tv.bn;
@@ -1150,7 +1150,7 @@ static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float*
     if (nsplit > 1) { a.out = slab; a.slab_stride = wsize; a.accumulate = 0; }
     else { a.out = dw; a.slab_stride = 0; a.accumulate = accumulate; }
     dim3 grid(wg.ctiles, (a.Cf + wg.bn - 1) / wg.bn, nsplit);
-    if (int e = launch_wgrad_taps(a, grid, st, wg.bm, wg.bn, d->transposed ? 1 : 0)) return e;
+    if (int e = launch_wgrad_taps(a, grid, st, wg.bm, wg.bn, d->transposed ? 1 : 0, (wvariant >> 3) & 1)) return e;
   } else if (pieces > 0) {
     dim3 grid(d->kernel * g.ctiles, (d->c_out + wg.bn - 1) / wg.bn, nsplit);
     if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces, d->tile[2] / 1000000)) return e;

@@ -166,6 +166,8 @@ _SPLIT_WGRAD_CODES = _TILES + tuple(1000000 + c for c in _TILES) + _WGRAD_BIG + 
 _SPLIT_WGRAD_CODES = _SPLIT_WGRAD_CODES + tuple(2000000 + c for c in _SPLIT_WGRAD_CODES)
 # 4BBBNNN / 6BBBNNN: all taps of a tile in one workgroup (wgrad_taps_bf16s_kernel), launch order / XCD-aware order
 _SPLIT_WGRAD_CODES = _SPLIT_WGRAD_CODES + (4128128, 4064128, 4128064, 6128128, 6064128, 6128064)
+# 12BBBNNN / 14BBBNNN: the all-taps kernel on the 16x16x32 MFMA shape
+_SPLIT_WGRAD_CODES = _SPLIT_WGRAD_CODES + (12128128, 12064128, 12128064, 14128128, 14064128, 14128064)
 # BatchNorm batch statistics (forward) and first-pass backward sums from the conv GEMMs' epilogues where their kernels support it
 # (SVAE_FUSE_BN=0: the separate passes, for A/B measurements)
 FUSE_BN_STATS = os.environ.get("SVAE_FUSE_BN", "1") != "0"
@@ -329,7 +331,7 @@ class Conv:
             kp = self._kind_pieces(kind)
             P, H = (2, "true") if kp == F16X2 else (kp, "false")
             if kp and kind == "wgrad" and (self.desc.tile[2] // 1000000) & 4:
-                names[kind] = (f"wgrad_taps_bf16s_kernel<{bm.value}, {bn.value}, {self.kernel}, "
+                names[kind] = (f"wgrad_taps{'16' if (self.desc.tile[2] // 1000000) & 8 else ''}_bf16s_kernel<{bm.value}, {bn.value}, {self.kernel}, "
                                f"{self.desc.stride}, {'true' if self.desc.transposed else 'false'}>")
             elif kp and kind == "wgrad":
                 waves = {256256: "2, 4", 256128: "4, 2", 128256: "2, 4"}.get(self.desc.tile[2] % 1000000, "2, 2")
