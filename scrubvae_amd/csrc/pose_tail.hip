@@ -141,6 +141,11 @@ __device__ __forceinline__ void c6_to_mat_bwd(const float* a, const M3& dM, floa
 // (__launch_bounds__(512, 3), 57 spilled registers) measured no faster (599 -> 636 us), so the cap is not set.  What the
 // per-frame cost really is made of -- ~12 k dependent VALU operations per frame behind scalar tree look-ups and ds_read_b32
 // operands, issued by 1.5 waves per SIMD -- is what a next round has to restructure (frames x joints parallelism inside a wave).
+// Round 2 also built the opposite extreme and measured it SLOWER (730 us vs 604 us, B = 4096): a lane owns a frame end to end, a
+// wave 64 frames with no barrier, every operand read per lane straight from global memory (8-byte pieces of the lane's own 576-byte
+// row), only the joint positions in LDS (17.7 KB per wave, 8 waves per CU).  Correct (it passed test_pose_tail), but each such load
+// instruction touches 64 different cache lines and the 8 waves' rows (295 KB) do not stay in the 32 KB L1: every 8-byte piece
+// re-fetches its line from L2, ~16x the bytes.  The LDS tile IS the coalescing buffer; what it costs is occupancy.
 template <int TR>
 __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const TailArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

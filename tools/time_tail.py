@@ -23,4 +23,4 @@ for _ in range(20): run()
 e.record(); torch.cuda.synchronize()
 us = s.elapsed_time(e) / 20 * 1e3
 byts = 2 * rows * (6 * J + 3 * J + 3 * J + 3 + 3) * 4
-print(f"SVAE_TAIL_ROWS={os.environ.get('SVAE_TAIL_ROWS', 'default')} B={B}: {us:.1f} us, {byts / us / 1e6:.2f} TB/s algorithmic ({byts / us / 1e6 / 8:.3f} of 8 TB/s)")
+print(f"SVAE_TAIL_KERNEL={os.environ.get('SVAE_TAIL_KERNEL', 'lane')} SVAE_TAIL_ROWS={os.environ.get('SVAE_TAIL_ROWS', 'default')} B={B}: {us:.1f} us, {byts / us / 1e6:.2f} TB/s algorithmic ({byts / us / 1e6 / 8:.3f} of 8 TB/s)")
