@@ -730,6 +730,7 @@ class ResVAE(nn.Module):
         """ResVAE.decode (residual.py:461-491)."""
         self._new_pass()
         B = z.shape[0]
+        self._ov = (B * self.window >= self.overlap_min_rows) if self.overlap_wgrad is None else bool(self.overlap_wgrad)
         zcp = pad16(self.z_dim + self.conditional_dim)
         zc = self._buf("dec.zc", (B, zcp), zero=True)
         zc[:, : self.z_dim] = z.to(self.device)
@@ -753,6 +754,7 @@ class ResVAE(nn.Module):
         """VAE.forward (residual.py:318-362).  Returns data_o with mu, L, z, x6d, root, var,
         disentangle[method][feature]."""
         self._new_pass()
+        self._ov = (data["x6d"].shape[0] * self.window >= self.overlap_min_rows) if self.overlap_wgrad is None else bool(self.overlap_wgrad)
         B, flat, h = self._encode_trunk(data)
         eps = None
         if self.training:

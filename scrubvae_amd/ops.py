@@ -212,6 +212,10 @@ def _timed(kind, conv, n_padded, fn):
     if t is None or kind not in t.kinds or (t.only is not None and conv.kernel_name(kind) != t.only):
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # The stream is drained first: a HIP event's timestamp is taken when the command processor reaches its marker, which for a marker
+    # queued behind a long kernel can be BEFORE that kernel has finished -- brackets of back-to-back GEMMs then overlap (measured: the
+    # brackets of one serialised step summed to 22 ms of a 15.3 ms step; a data-gradient launch read 950 us where rocprofv3 reports 510).
+    torch.cuda.current_stream().synchronize()
     s.record()
     r = fn()
     e.record()
