@@ -384,6 +384,13 @@ int svae_adam_advance(float* hyper, float beta1, float beta2, void* stream);
 /* torch.nn.utils.clip_grad_norm_ (trainer.py:164): g *= min(1, max_norm / (sqrt(*sumsq) + 1e-6)); sumsq = device scalar
  * holding the sum of squares of ALL gradients.  Returns without touching g when the clip does not bite. */
 int svae_clip_grads(float* g, long long n, const float* sumsq, float max_norm, void* stream);
+
+/* Batched small dense solves for the streaming scrubbers (reference: MovingAvgLeastSquares.forward,
+ * src/scrubvae/model/disentangle.py:466-486 -- torch.linalg.solve(Sxx + l2 I, Sxy) twice per step; direct_lsq_loss,
+ * src/scrubvae/train/losses.py:173-179).  System s: (A[s] + diag(diag)) X[s] = B[s], A row-major [n][n], B / X row-major
+ * [n][nrhs], strides in elements between systems; diag may be NULL; n, nrhs <= 64.  LU with partial pivoting, fp32. */
+int svae_small_solve(const float* A, long long strideA, const float* diag, const float* B, long long strideB, float* X,
+                     long long strideX, int n, int nrhs, int batch, void* stream);
 /* sum of squares partials for clip_grad_norm_ (trainer.py:164): part[svae_sumsq_blocks(n)] */
 int svae_sumsq_blocks(long long n);
 int svae_sumsq_partial(const float* x, long long n, float* part, void* stream);

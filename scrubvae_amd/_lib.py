@@ -137,6 +137,7 @@ SIGNATURES = {
     "svae_adam_step_dev": (I, [P, P, P, P, LL, P, F, F, F, F, I, F, P]),
     "svae_adam_advance": (I, [P, F, F, P]),
     "svae_clip_grads": (I, [P, LL, P, F, P]),
+    "svae_small_solve": (I, [P, LL, P, P, LL, P, LL, I, I, I, P]),
     "svae_sumsq_blocks": (I, [LL]),
     "svae_sumsq_partial": (I, [P, LL, P, P]),
     "svae_reduce_rows": (I, [P, I, I, F, P, I, P]),

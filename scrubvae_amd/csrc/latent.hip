@@ -269,3 +269,79 @@ extern "C" int svae_tc_bwd(const float* z, int ldz, const float* mu, int ldm, co
                      weight, d_mu, ldd, d_lv, ldv, sigma, lds);
   return check_launch("tc_bwd");
 }
+
+// ---------------------------------------------------------------- batched small dense solves
+// The streaming scrubbers solve z x z (plus a bias column) normal equations every step -- MovingAvgLeastSquares.forward
+// (reference model/disentangle.py:466-486: two systems, W = (Sxx + l2 I)^-1 Sxy) and direct_lsq_loss (train/losses.py:173-179) --
+// which torch.linalg.solve turns into a handful of solver-library launches per system.  One workgroup per system here: LU with partial
+// pivoting on the augmented matrix [A + diag | B] held in LDS (n <= 64 rows = lanes of wave 0 for the pivot search, the row
+// updates spread over 256 threads), the same elimination order as the reference's LAPACK getrf / getrs without blocking, fp32.
+// A singular pivot (exactly zero) yields inf / nan like the library does.
+constexpr int SOLVE_MAXN = 64, SOLVE_MAXRHS = 64;
+__global__ __launch_bounds__(256) void small_solve_kernel(const float* __restrict__ A, long long strideA, const float* __restrict__ diag,
+                                                           const float* __restrict__ Bm, long long strideB, float* __restrict__ X,
+                                                           long long strideX, int n, int nrhs) {
+  __shared__ float M[SOLVE_MAXN][SOLVE_MAXN + SOLVE_MAXRHS + 1];
+  __shared__ int piv;
+  const int tid = threadIdx.x, w = n + nrhs;
+  const float* a = A + blockIdx.x * strideA;
+  const float* b = Bm + blockIdx.x * strideB;
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, j = e - i * n;
+    M[i][j] = a[e] + ((diag && i == j) ? diag[i] : 0.f);
+  }
+  for (int e = tid; e < n * nrhs; e += 256) {
+    const int i = e / nrhs, j = e - i * nrhs;
+    M[i][n + j] = b[e];
+  }
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    if (tid < 64) {  // pivot: the first row of maximal |M[i][k]|, i >= k
+      float v = (tid >= k && tid < n) ? fabsf(M[tid][k]) : -1.f;
+      int idx = tid;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+      }
+      if (tid == 0) piv = idx;
+    }
+    __syncthreads();
+    const int p = piv;
+    if (p != k)
+      for (int j = tid; j < w; j += 256) { const float t = M[k][j]; M[k][j] = M[p][j]; M[p][j] = t; }
+    __syncthreads();
+    const float inv = 1.f / M[k][k];
+    // rows i > k: l = M[i][k] / pivot, M[i][j] -= l M[k][j] for j > k (the multiplier column is not kept)
+    const int rows = n - k - 1, cols = w - k - 1;
+    for (int e = tid; e < rows * cols; e += 256) {
+      const int i = k + 1 + e / cols, j = k + 1 + e % cols;
+      M[i][j] -= (M[i][k] * inv) * M[k][j];
+    }
+    __syncthreads();
+  }
+  // back substitution, one right-hand side per thread
+  if (tid < nrhs) {
+    const int c = n + tid;
+    for (int i = n - 1; i >= 0; --i) {
+      float sacc = M[i][c];
+      for (int j = i + 1; j < n; ++j) sacc -= M[i][j] * M[j][c];
+      M[i][c] = sacc / M[i][i];
+    }
+  }
+  __syncthreads();
+  float* x = X + blockIdx.x * strideX;
+  for (int e = tid; e < n * nrhs; e += 256) {
+    const int i = e / nrhs, j = e - i * nrhs;
+    x[e] = M[i][n + j];
+  }
+}
+
+extern "C" int svae_small_solve(const float* A, long long strideA, const float* diag, const float* B, long long strideB, float* X,
+                                long long strideX, int n, int nrhs, int batch, void* stream) {
+  SVAE_REQUIRE(A && B && X && n >= 1 && n <= SOLVE_MAXN && nrhs >= 1 && nrhs <= SOLVE_MAXRHS && batch >= 1, SVAE_ERR_ARG,
+               "small_solve: n <= %d, nrhs <= %d", SOLVE_MAXN, SOLVE_MAXRHS);
+  hipLaunchKernelGGL(small_solve_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, A, strideA, diag, B, strideB, X, strideX, n, nrhs);
+  return check_launch("small_solve");
+}

@@ -285,8 +285,12 @@ class MovingAvgLeastSquares(nn.Module):
         l2 = torch.ones(x.shape[1], device=x.device) * self.l2_reg
         if self.bias:
             l2[-1] = 0
-        W0 = torch.linalg.solve(self.Sxx0.diagonal_scatter(self.Sxx0.diagonal() + l2), self.Sxy0)
-        W1 = torch.linalg.solve(self.Sxx1.diagonal_scatter(self.Sxx1.diagonal() + l2), self.Sxy1)
+        if x.is_cuda and x.shape[1] <= 64 and self.Sxy0.shape[1] <= 64:  # both normal equations in one launch of the batched LU kernel
+            W = ops.small_solve(torch.stack((self.Sxx0, self.Sxx1)), torch.stack((self.Sxy0, self.Sxy1)), l2)
+            W0, W1 = W[0], W[1]
+        else:  # host tensors (CPU unit tests of the scrubber logic) / designs wider than the kernel's 64 columns
+            W0 = torch.linalg.solve(self.Sxx0.diagonal_scatter(self.Sxx0.diagonal() + l2), self.Sxy0)
+            W1 = torch.linalg.solve(self.Sxx1.diagonal_scatter(self.Sxx1.diagonal() + l2), self.Sxy1)
         self._W = (W0, W1)
         return [x @ W0, x @ W1]
 

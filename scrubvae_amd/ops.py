@@ -704,6 +704,19 @@ def clip_grads(g, sumsq, max_norm):
     check(_lib.lib().svae_clip_grads(_p(g), g.numel(), _p(sumsq), float(max_norm), _stream()), "clip_grads")
 
 
+def small_solve(A, B, diag=None):
+    """X with (A[s] + diag(diag)) X[s] = B[s]: A [S, n, n] (or [n, n]), B [S, n, nrhs] (or [n, nrhs]) fp32 on the device,
+    n, nrhs <= 64 -- one launch of the batched LU kernel (csrc/latent.hip) instead of a solver-library call per system."""
+    single = A.dim() == 2
+    A3 = (A[None] if single else A).contiguous().float()
+    B3 = (B[None] if single else B).contiguous().float()
+    S, n, nrhs = A3.shape[0], A3.shape[1], B3.shape[2]
+    X = torch.empty_like(B3)
+    d = None if diag is None else diag.contiguous().float()
+    check(_lib.lib().svae_small_solve(_p(A3), n * n, _p(d), _p(B3), n * nrhs, _p(X), n * nrhs, n, nrhs, S, _stream()), "small_solve")
+    return X[0] if single else X
+
+
 def sumsq_blocks(n):
     return int(_lib.lib().svae_sumsq_blocks(n))
 

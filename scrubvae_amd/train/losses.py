@@ -268,7 +268,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 if world > 1:  # normal equations of the GLOBAL batch
                     model._allreduce(zz)
                     model._allreduce(zy)
-                Wd = torch.linalg.solve(zz, zy)
+                Wd = ops.small_solve(zz, zy) if (zz.is_cuda and zz.shape[0] <= 64 and zy.shape[1] <= 64) else torch.linalg.solve(zz, zy)
                 res = zm @ Wd - tgt
                 v = _scalar(model, lk)
                 v.copy_((res * res).sum().reshape(1))

@@ -231,6 +231,30 @@ def test_upsample2(ops, B, L, Cc):
     assert relerr(from_nlc(dxd, B, L, Cc), x.grad) < 1e-6
 
 
+@pytest.mark.parametrize("n,nrhs,batch,with_diag", [(32, 3, 2, True), (33, 1, 2, True), (5, 7, 1, False), (64, 64, 3, False), (1, 1, 1, True)])
+def test_small_solve_vs_fp64(ops, n, nrhs, batch, with_diag):
+    """Batched LU solve of the streaming scrubbers' normal equations (svae_small_solve; reference: torch.linalg.solve in
+    MovingAvgLeastSquares.forward, disentangle.py:466-486, and direct_lsq_loss, losses.py:173-179) against fp64: Gram matrices of
+    random designs (condition numbers of 1e2-1e4, like exponentially-forgotten latent covariances) plus a non-symmetric system
+    that needs the row pivoting."""
+    g = torch.Generator().manual_seed(100 * n + nrhs)
+    X = torch.randn(batch, 4 * n + 8, n, generator=g, dtype=torch.float64)
+    A = X.transpose(1, 2) @ X
+    A[-1] = torch.randn(n, n, generator=g, dtype=torch.float64) + torch.diag(torch.zeros(n, dtype=torch.float64))  # general matrix
+    if n > 1:
+        A[-1][0, 0] = 0.0  # the first pivot must come from another row
+    B = torch.randn(batch, n, nrhs, generator=g, dtype=torch.float64)
+    d = torch.rand(n, generator=g, dtype=torch.float64) if with_diag else None
+    ref = torch.linalg.solve(A + (torch.diag(d) if with_diag else 0), B)
+    out = ops.small_solve(A.float().cuda(), B.float().cuda(), None if d is None else d.float().cuda())
+    f32 = torch.linalg.solve((A + (torch.diag(d) if with_diag else 0)).float(), B.float()).double()  # the reference's own fp32 arithmetic
+    e_hip = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+    e_f32 = float((f32 - ref).abs().max() / ref.abs().max())
+    assert e_hip < max(20 * e_f32, 1e-5), (e_hip, e_f32)
+    one = ops.small_solve(A[0].float().cuda(), B[0].float().cuda(), None if d is None else d.float().cuda())
+    assert torch.equal(one, out[0])  # the unbatched call is the same kernel on one system
+
+
 def test_heads_diag(ops):
     B, z = 37, 8
     h = torch.randn(B, 2 * z, dtype=torch.float64, requires_grad=True)
