@@ -1784,6 +1784,12 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
   const long long r_begin = (long long)bzi * g.rows_per_split;
   long long r_end = r_begin + g.rows_per_split;
   if (r_end > g.R) r_end = g.R;
+  // flat_np > 0 (transposed convs with many taps: the 22-tap output conv): the taps are FOLDED INTO THE COLUMNS of the dY operand --
+  // column c' = t * flat_np + c_out of a virtual [rows][T * flat_np] matrix whose row j starts at dY row j + by[0]: the tile columns
+  // then pad T * c_out to a multiple of BN once instead of c_out per tap (141 -> 256 per tap with BN = 128 is 44 % idle columns,
+  // 22 * 144 -> 3200 is 1 %), X is staged once for 128 flat columns instead of once per tap, and a staging thread masks its rows with
+  // the tap of ITS channel quad (flat_np is a multiple of 4: a quad never straddles two taps).
+  const int np = g.flat_np;
   const int tbx = g.bx[ti], tby = g.by[ti];
 
   // staging unit of this thread: operand (A = X channels, B = dY channels), row group rg, channel quad cq
@@ -1796,13 +1802,19 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
   const int nq8 = (is_a ? BM : BN) / 32;  // groups of 8 channel quads in the tile
   const int cq = (l16 & 7) + 8 * (q16 % nq8);
   const int rg = ((l16 >> 3) & 1) + 2 * (q16 / nq8);
-  const int ch0 = (is_a ? c0 : n0) + cq * 4;
+  int ch0 = (is_a ? c0 : n0) + cq * 4;
   const bool col_ok = has_unit && ch0 < (is_a ? g.Kc : g.N);
+  int tb_unit = is_a ? tbx : tby;          // tap offset of this unit's operand rows
+  if (np > 0 && !is_a) {
+    const int tcol = ch0 / np;             // the tap this dY channel quad belongs to (affine tap offsets: by[t] = by[0] + t (by[1] - by[0]))
+    tb_unit = g.by[0] + tcol * (g.T > 1 ? g.by[1] - g.by[0] : 0);
+    ch0 -= tcol * np;
+  }
   const float* const base = is_a ? g.X : g.dY;
   const int ld = is_a ? g.ldX : g.ldY;
   const int L = is_a ? g.Lx : g.Ly;
   const int s = is_a ? g.sx : g.sy;
-  const int tb = is_a ? tbx : tby;
+  const int tb = tb_unit;
   const long long row_step = (long long)s * ld;                       // next reduction row, same sample
   const long long row_wrap = ((long long)L - (long long)g.nj * s) * ld;  // extra when j wraps into the next sample
   const int qs16 = WSK / g.nj, r16 = WSK % g.nj;
@@ -1818,9 +1830,11 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
     const long long l = r_end - r;
     left = l > 0x7fffffffLL ? 0x7fffffff : (int)l;
     xr0 = jj * g.sx + tbx;
-    yr0 = jj * g.sy + tby;
+    yr0 = jj * g.sy + (np > 0 ? (is_a ? 0 : tb_unit) : tby);  // flat mode: the X rows are shared by columns of different taps: never masked by one
   }
   const int dx16 = r16 * g.sx, dy16 = r16 * g.sy, wrapx = g.nj * g.sx, wrapy = g.nj * g.sy;
+  const int yr_base = np > 0 ? (is_a ? 0 : tb_unit) : tby;
+  const bool y_free = np > 0 && is_a;  // (flat mode, X unit: its rows are valid for every tap)
   const int lds_unit = (is_a ? 0 : P * A_PIECE) + lds_row(cq * 4) + rg * 8;
   const float* const zero_row = wgrad_zero_row;
 
@@ -1832,7 +1846,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
     const float* p = ptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = col_ok & (left > i) & ((unsigned)xr < (unsigned)g.Lx) & ((unsigned)yr < (unsigned)g.Ly);
+      const bool ok = col_ok & (left > i) & ((unsigned)xr < (unsigned)g.Lx) & (((unsigned)yr < (unsigned)g.Ly) | y_free);
       rv[i] = *reinterpret_cast<const float4*>(ok ? p : zero_row);
       ++j;
       p += row_step;
@@ -1842,7 +1856,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
       j = wrap ? 0 : j;
       p += wrap ? row_wrap : 0;
       xr = wrap ? tbx : xr;
-      yr = wrap ? tby : yr;
+      yr = wrap ? yr_base : yr;
     }
     jj += r16;
     ptr += st_step;
@@ -1931,8 +1945,13 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
   float* out = g.out + (long long)bzi * g.slab_stride + (long long)ti * g.Kc * g.ldW;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int col = n0 + wc * WN + nt * 32 + lr;
+    int col = n0 + wc * WN + nt * 32 + lr;
     if (col >= g.N) continue;
+    if (np > 0) {  // flat column -> (tap, output channel)
+      const int t = col / np;
+      col -= t * np;
+      out = g.out + (long long)bzi * g.slab_stride + (long long)t * g.Kc * g.ldW;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -2445,7 +2464,7 @@ static int launch_wgrad_big(const WgradArgs& g, dim3 grid, hipStream_t st, int p
 // variant 0: double-buffered LDS; 1: single LDS buffer
 int launch_wgrad_split(const WgradArgs& g_in, dim3 grid, hipStream_t st, int bm, int bn, int pieces, int variant) {
   WgradArgs g = g_in;
-  g.xmap = (variant >> 1) & 1;  // variants 2 / 3: as 0 / 1 with the XCD-aware workgroup order
+  g.xmap = (variant >> 1) & 1;  // variants 2 / 3: as 0 / 1 with the XCD-aware workgroup order (bit 16: taps folded into the columns, set up by the caller)
   variant &= 1;
 #define SVAE_WG_CASE(BM_, BN_)                                            \
   if (bm == BM_ && bn == BN_) {                                           \

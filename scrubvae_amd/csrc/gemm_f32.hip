@@ -1063,6 +1063,7 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
   long long tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
   Tile ov;
   const int tcode = d->tile[2] > 0 ? d->tile[2] % 1000000 : 0;
+  const bool flat = d->tile[2] > 0 && ((d->tile[2] / 1000000) & 16) && !((d->tile[2] / 1000000) & 4);  // taps folded into the dY columns
   const bool big = tcode == 256256 || tcode == 256128 || tcode == 128256;  // 8-wave split-bf16 tiles (gemm_bf16s.hip)
   if (big) {
     w.bm = tcode / 1000; w.bn = tcode % 1000;
@@ -1077,6 +1078,7 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
     w.ctiles = (d->c_in + 63) / 64;
     tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
   }
+  if (flat) tiles = (long long)w.ctiles * (((long long)d->kernel * d->c_out + w.bn - 1) / w.bn);
   // resident blocks: 3 per CU for the 128x128 tile (144 VGPR+AGPR), 4 for the smaller ones
   const long long slots = big ? 256 : 256 * ((w.bm == 128 && w.bn == 128) ? 3 : 4);  // 8-wave tiles: one workgroup per CU
   long long want = tiles >= slots ? 1 : slots / tiles;
@@ -1151,6 +1153,12 @@ static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float*
     else { a.out = dw; a.slab_stride = 0; a.accumulate = accumulate; }
     dim3 grid(wg.ctiles, (a.Cf + wg.bn - 1) / wg.bn, nsplit);
     if (int e = launch_wgrad_taps(a, grid, st, wg.bm, wg.bn, d->transposed ? 1 : 0, (wvariant >> 3) & 1)) return e;
+  } else if (pieces > 0 && (wvariant & 16)) {
+    SVAE_REQUIRE(d->transposed && d->kernel >= 2, SVAE_ERR_SHAPE, "conv_wgrad: the flat-tap variant is built for transposed convs (x rows tap-independent)");
+    g.flat_np = d->c_out;
+    g.N = d->kernel * d->c_out;
+    dim3 grid(g.ctiles, (g.N + wg.bn - 1) / wg.bn, nsplit);
+    if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces, wvariant & 3)) return e;
   } else if (pieces > 0) {
     dim3 grid(d->kernel * g.ctiles, (d->c_out + wg.bn - 1) / wg.bn, nsplit);
     if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces, d->tile[2] / 1000000)) return e;
