@@ -202,6 +202,22 @@ __global__ __launch_bounds__(256) void affine_prelu_fwd_kernel(const float* __re
   const bool th = alpha == nullptr;
   const float a = th ? 0.f : alpha[0];
   const long long total = rows * C4;
+  if ((C4 & (C4 - 1)) == 0 && C4 <= 256) {
+    // power-of-two channel quads (every BatchNorm of the model): a thread keeps ONE channel quad for all its rows -- its coefficients
+    // are loaded once and the loop has no 64-bit division (the generic loop below spends more on `i / C4` than on the memory access)
+    const int sh = __ffs(C4) - 1;
+    const int c = (threadIdx.x & (C4 - 1)) * 4;
+    float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale != nullptr) { s4 = ld4(scale + c); t4 = ld4(shift + c); }
+    const long long rstep = ((long long)gridDim.x * 256) >> sh;
+    for (long long r = ((long long)blockIdx.x * 256 + threadIdx.x) >> sh; r < rows; r += rstep) {
+      float4 v = ld4(x + r * ld + c);
+      v.x = act_fwd(v.x * s4.x + t4.x, a, th); v.y = act_fwd(v.y * s4.y + t4.y, a, th);
+      v.z = act_fwd(v.z * s4.z + t4.z, a, th); v.w = act_fwd(v.w * s4.w + t4.w, a, th);
+      st4(y + r * ld + c, v);
+    }
+    return;
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / C4;
     const int c = (int)(i - r * C4) * 4;
@@ -282,6 +298,46 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_apply_kernel(
   const float a = th ? 0.f : alpha[0];
   const int C4 = C / 4;
   const long long total = rows * C4;
+  if ((C4 & (C4 - 1)) == 0 && C4 <= 256) {  // one channel quad per thread: coefficients hoisted, no 64-bit division (see affine_prelu_fwd_kernel)
+    const int sh = __ffs(C4) - 1;
+    const int c = (threadIdx.x & (C4 - 1)) * 4;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, shf[4] = {0.f, 0.f, 0.f, 0.f};
+    if (scale != nullptr) {
+      const float4 a4 = ld4(scale + c), b4 = ld4(shift + c);
+      sc[0] = a4.x; sc[1] = a4.y; sc[2] = a4.z; sc[3] = a4.w;
+      shf[0] = b4.x; shf[1] = b4.y; shf[2] = b4.z; shf[3] = b4.w;
+    }
+    // (same expression and evaluation order as the generic loop below: bit-identical results)
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f},
+          s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sums != nullptr) {
+      const float4 m4 = ld4(mean + c), r4 = ld4(rstd + c), g4 = ld4(gamma + c), p4 = ld4(sums + c), q4 = ld4(sums + C + c);
+      mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+      rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
+      gm[0] = g4.x; gm[1] = g4.y; gm[2] = g4.z; gm[3] = g4.w;
+      s0[0] = p4.x; s0[1] = p4.y; s0[2] = p4.z; s0[3] = p4.w;
+      s1[0] = q4.x; s1[1] = q4.y; s1[2] = q4.z; s1[3] = q4.w;
+    }
+    const long long rstep = ((long long)gridDim.x * 256) >> sh;
+    for (long long r = ((long long)blockIdx.x * 256 + threadIdx.x) >> sh; r < rows; r += rstep) {
+      const float4 xv4 = ld4(x + r * ld + c), dv4 = ld4(dy + r * ld + c);
+      const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float u = xv[k] * sc[k] + shf[k];
+        const float du = dv[k] * act_grad(u, a, th);
+        if (sums != nullptr) {
+          const float xh = (xv[k] - mu[k]) * rs[k];
+          o[k] = gm[k] * rs[k] * (du - s0[k] * inv_count - xh * s1[k] * inv_count);
+        } else {
+          o[k] = du * sc[k];
+        }
+      }
+      st4(dx + r * ld + c, make_float4(o[0], o[1], o[2], o[3]));
+    }
+    return;
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / C4;
     const int c = (int)(i - r * C4) * 4;
@@ -345,6 +401,22 @@ __global__ __launch_bounds__(128) void bn_param_grads_kernel(const float* __rest
 __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int batch, int L,
                                                              int C4, int ld) {
   const long long total = (long long)batch * 2 * L * C4;
+  if ((C4 & (C4 - 1)) == 0 && C4 <= 256 && (long long)batch * 2 * L < 0x7fffffffLL) {
+    // one channel quad per thread, 32-bit row arithmetic (the generic loop's two 64-bit divisions cost more than its memory accesses)
+    const int sh = __ffs(C4) - 1;
+    const int c = (threadIdx.x & (C4 - 1)) * 4;
+    const unsigned nrow = (unsigned)batch * 2u * (unsigned)L, rstep = (unsigned)(((long long)gridDim.x * 256) >> sh), L2 = 2u * (unsigned)L;
+    for (unsigned row = (unsigned)(((long long)blockIdx.x * 256 + threadIdx.x) >> sh); row < nrow; row += rstep) {
+      const unsigned b = row / L2;
+      const int ro = (int)(row - b * L2);
+      const int ii = ro >> 1;
+      const int i2 = (ro & 1) ? (ii + 1 < L ? ii + 1 : L - 1) : (ii > 0 ? ii - 1 : 0);
+      const float4 p = ld4(x + ((long long)b * L + ii) * ld + c), q = ld4(x + ((long long)b * L + i2) * ld + c);
+      st4(y + (long long)row * ld + c, make_float4(0.75f * p.x + 0.25f * q.x, 0.75f * p.y + 0.25f * q.y, 0.75f * p.z + 0.25f * q.z,
+                                                    0.75f * p.w + 0.25f * q.w));
+    }
+    return;
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long row = i / C4;
     const int c = (int)(i - row * C4) * 4;
@@ -361,6 +433,27 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int batch, int L,
                                                              int C4, int ld, int accumulate) {
   const long long total = (long long)batch * L * C4;
+  if ((C4 & (C4 - 1)) == 0 && C4 <= 256 && (long long)batch * L < 0x7fffffffLL) {  // as in upsample2_fwd_kernel
+    const int sh = __ffs(C4) - 1;
+    const int c = (threadIdx.x & (C4 - 1)) * 4;
+    const unsigned nrow = (unsigned)batch * (unsigned)L, rstep = (unsigned)(((long long)gridDim.x * 256) >> sh);
+    for (unsigned row = (unsigned)(((long long)blockIdx.x * 256 + threadIdx.x) >> sh); row < nrow; row += rstep) {
+      const unsigned b = row / (unsigned)L;
+      const int ii = (int)(row - b * (unsigned)L);
+      const float* base = dy + (long long)b * 2 * L * ld + c;
+      const float4 e = ld4(base + (long long)(2 * ii) * ld), o = ld4(base + (long long)(2 * ii + 1) * ld);
+      const float4 nx = ld4(base + (long long)(ii + 1 < L ? 2 * ii + 2 : 2 * L - 1) * ld);
+      const float4 pv = ld4(base + (long long)(ii >= 1 ? 2 * ii - 1 : 0) * ld);
+      float4 r = make_float4(0.75f * (e.x + o.x) + 0.25f * (nx.x + pv.x), 0.75f * (e.y + o.y) + 0.25f * (nx.y + pv.y),
+                             0.75f * (e.z + o.z) + 0.25f * (nx.z + pv.z), 0.75f * (e.w + o.w) + 0.25f * (nx.w + pv.w));
+      if (accumulate) {
+        const float4 old = ld4(dx + (long long)row * ld + c);
+        r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w;
+      }
+      st4(dx + (long long)row * ld + c, r);
+    }
+    return;
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long row = i / C4;
     const int c = (int)(i - row * C4) * 4;
