@@ -96,7 +96,7 @@ int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const float* dy, fl
  * `wsplit` (svae_conv_split_bytes(d) bytes, caller-owned) holds the weight pieces written by
  * svae_conv_split_weights from the fp32 master weights w[tap][c_in][c_out]; refresh it whenever
  * the weights change.  d->tile[0..1]: V*1000000 + BM*1000 + BN, V = kernel variant (waves per
- * workgroup / LDS buffering, see gemm_bf16s.hip; 16 / 17: the 12-wave halo kernel with DMA-only loader waves, 256-row
+ * workgroup / LDS buffering, see gemm_bf16s.hip; 16 / 17 / 18 (18: on the 16x16x32 MFMA): the 12-wave halo kernel with DMA-only loader waves, 256-row
  * tiles).  d->tile[2] for the split weight gradient: V*1000000 + BM*1000 + BN with V a bit set -- 1: single LDS buffer,
  * 2: XCD-aware workgroup order, 4: all taps of a tile in one workgroup (contiguous 5 / 6-tap geometries, 2 pieces;
  * SVAE_ERR_SHAPE otherwise), 8: that kernel on the 16x16x32 MFMA shape, 16: (transposed convs) the taps folded into

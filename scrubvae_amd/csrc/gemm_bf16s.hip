@@ -2423,6 +2423,401 @@ __global__ __launch_bounds__(512) void wgrad_taps16_bf16s_kernel(const WgradTaps
   }
 }
 
+// ------------------------------------------- the 12-wave halo kernel on v_mfma_f32_16x16x32 (tile code 18)
+// Same structure as gather_halo_ws4_bf16s_kernel (loaders, staging ring, consumer-side conversion, zero-row reads); the matrix work
+// runs on the 16x16x32 shape, which holds a higher clock at equal cycles per FLOP where the chip is power-limited.
+// Fragment = 16 rows x 32 k: lane l reads the 16-byte chunk l / 16 of row l % 16 -- one ds_read_b128 per 16-row block, piece and stage.
+// The chunk swizzle differs from swz(): with chunks 0 / 1 of rows 0-3 / 4-11 / 12-15 in one ds_read_b128 lane group, the map
+// row / 4 -> (0, 3, 2, 1) keeps the 16 lanes of a group on 16 different 16-byte slots.
+__device__ __forceinline__ int swz16(int row) { return (0 - (row >> 2)) & 3; }
+__device__ __forceinline__ f32x4v mfma16_f16(uint4 a, uint4 b, f32x4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <bool H>
+__device__ __forceinline__ f32x4v mfma16_split2x(const uint4 (&a)[2], const uint4 (&b)[2], f32x4v acc) {  // small terms first
+  if constexpr (H) {
+    acc = mfma16_f16(a[1], b[0], acc);
+    acc = mfma16_f16(a[0], b[1], acc);
+    acc = mfma16_f16(a[0], b[0], acc);
+    return acc;
+  } else {
+    return mfma16_split2(a, b, acc);
+  }
+}
+
+// tile_epilogue for 16 x 16 accumulator tiles: column = lane % 16, row = 4 (lane / 16) + register
+template <int MB, int NBK, int WM, int WN, int WR, int BN>
+__device__ __forceinline__ void tile_epilogue16(const GatherArgs& g, f32x4v (&acc)[MB][NBK], const long long* rowoff, int n0, int wr, int wc,
+                                                int lane, float* red, int tid, int nth, float oscale, int tile_x, int tile_y) {
+  const int l16 = lane & 15, rg = lane >> 4;
+  float cs[NBK], cq[NBK];
+  float da = 0.f;
+  const bool bwd = g.bn_x != nullptr;        // uniform
+  const bool th = g.bn_alpha == nullptr;     // tanh instead of PReLU
+  const float slope = (bwd && !th) ? g.bn_alpha[0] : 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) {
+    const int col = n0 + wc * WN + nb * 16 + l16;
+    cs[nb] = 0.f;
+    cq[nb] = 0.f;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+    float sc = 1.f, sh = 0.f, mu = 0.f, rs = 0.f;
+    if (bwd) {
+      if (g.bn_scale) { sc = g.bn_scale[col]; sh = g.bn_shift[col]; }
+      if (g.bn_mean) { mu = g.bn_mean[col]; rs = g.bn_rstd[col]; }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr * WM + mb * 16 + 4 * rg + r;
+        const long long off = rowoff[row];
+        if (off >= 0) {
+          float* dst = g.C + off + col;
+          float v = acc[mb][nb][r] * oscale + bv;
+          if (g.accumulate) v += *dst;
+          *dst = v;
+          if (bwd) {
+            const float x = g.bn_x[off + col];
+            const float u = x * sc + sh;
+            float du;
+            if (th) { const float t = tanhf(u); du = v * (1.f - t * t); }
+            else { du = u > 0.f ? v : slope * v; if (!(u > 0.f)) da += v * u; }
+            cs[nb] += du;
+            cq[nb] += du * (x - mu) * rs;
+          } else {
+            cs[nb] += v;
+            cq[nb] += v * v;
+          }
+        }
+      }
+    }
+  }
+  if (g.stats == nullptr) return;  // uniform
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) {
+    cs[nb] += __shfl_xor(cs[nb], 16, 64);
+    cq[nb] += __shfl_xor(cq[nb], 16, 64);
+    cs[nb] += __shfl_xor(cs[nb], 32, 64);
+    cq[nb] += __shfl_xor(cq[nb], 32, 64);
+  }
+  __syncthreads();  // every wave is past its last LDS operand read: the staging buffers are free
+  if (rg == 0) {
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+      const int c = wc * WN + nb * 16 + l16;
+      red[(0 * WR + wr) * BN + c] = cs[nb];
+      red[(1 * WR + wr) * BN + c] = cq[nb];
+    }
+  }
+  float* dred = red + 2 * WR * BN;  // one slot per wave for the slope partial
+  if (bwd && g.bn_dalpha) {
+    da = wave_sum(da);
+    if ((tid & 63) == 0) dred[tid >> 6] = da;
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * BN; i += nth) {
+    const int k = i / BN, c = i - k * BN;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WR; ++w) t += red[(k * WR + w) * BN + c];
+    if (n0 + c < g.N) g.stats[((long long)tile_x * 2 + k) * g.N + n0 + c] = t;
+  }
+  if (bwd && g.bn_dalpha && tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < nth / 64; ++w) t += dred[w];
+    g.bn_dalpha[(long long)tile_x * gridDim.y + tile_y] = t;
+  }
+}
+
+template <int BM, int BN, int RMAX, int STG, bool H>
+__global__ __launch_bounds__(768) void gather_halo_ws4m_bf16s_kernel(const SplitGatherArgs sa) {
+  const GatherArgs& g = sa.g;
+  constexpr int P = 2, NB = 3, WR = 4, WC = 2, NPW = 4;
+  constexpr int NCT = 64 * WR * WC;   // consumer threads
+  constexpr int WM = BM / WR, MB = WM / 16, WN = BN / WC, NBK = WN / 16;
+  static_assert(MB >= 1 && NBK >= 1 && WM % 16 == 0 && WN % 16 == 0, "wave tile must be a multiple of 16x16");
+  static_assert(BM <= NCT, "rowoff is filled by the consumer threads");
+  static_assert(RMAX % 8 == 0 && STG % 8 == 0, "a DMA wave-instruction carries 8 image rows");
+  constexpr int ROWB = SBK * 2;                    // bytes of an image / weight row per piece
+  constexpr int RAWB = SBK * 4;                    // bytes of a raw fp32 row
+  constexpr int A_PIECE = (RMAX + 1) * ROWB, B_PIECE = BN * ROWB;  // image row RMAX: zeros, the target of operand reads that hit conv padding
+  constexpr int ZROW = RMAX * ROWB;
+  constexpr int A_IMG = P * A_PIECE, B_STAGE = P * B_PIECE;
+  constexpr int STG_BYTES = STG * RAWB;
+  static_assert(RMAX * RAWB <= A_IMG, "the prologue stages the raw image of block 0 in image buffer 1");
+  static_assert(2 * A_IMG + NB * B_STAGE + 3 * STG_BYTES + BM * 8 <= 160 * 1024, "LDS budget");
+  constexpr int B_INSTR = B_STAGE / 1024;          // 1-KiB DMA wave-instructions per weight stage
+  static_assert(B_STAGE % (1024 * NPW) == 0, "weight stage must split evenly over the loader waves");
+  constexpr int BPW = B_INSTR / NPW;               // per loader wave
+  constexpr int SPW = (STG / 8 + NPW - 1) / NPW;   // raw-slice wave-instructions per loader wave, at most
+  constexpr int CPT = (STG * 8 + NCT - 1) / NCT;   // float4 conversions per consumer thread and stage, at most
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * A_IMG + NB * B_STAGE + 3 * STG_BYTES];
+  __shared__ long long rowoff[BM];
+  unsigned char* const bbase = smem + 2 * A_IMG;
+  unsigned char* const sbase = bbase + NB * B_STAGE;
+
+  const int tid = threadIdx.x;
+  // (An XCD-aware tile order -- every XCD a contiguous run of the column-major tile list, so that its workgroups stream the same
+  //  weight tiles -- was measured 2-8 % SLOWER: each XCD then reads every activation image once per column tile from beyond its
+  //  L2, where the launch order already gives an XCD 8 row tiles x 4 column tiles at a time, each line shared by 4-8 workgroups.)
+  const int tile_x = blockIdx.x, tile_y = blockIdx.y;
+  int bx = tile_x, phase = 0;
+  if (bx >= g.blocks_m[0]) { phase = 1; bx -= g.blocks_m[0]; }
+  const long long m0 = (long long)bx * BM;
+  const int n0 = tile_y * BN;
+  const long long Mp = g.M[phase];
+  const int nj = g.nj[phase];
+  const int ntaps = g.ntaps[phase];
+  const int tb0 = g.base0[phase], tbs = g.bstep[phase], tw0 = g.w0[phase], tws = g.wstep[phase];
+  const int tbl = tb0 + (ntaps - 1) * tbs;
+  const int bmin = tb0 < tbl ? tb0 : tbl, bmax = tb0 < tbl ? tbl : tb0;
+  const long long b0 = m0 / nj;
+  const long long amin = b0 * g.Lin + (long long)(m0 - b0 * nj) * g.sj;
+  const long long ml = (m0 + BM < Mp ? m0 + BM : Mp) - 1;
+  const long long bl = ml / nj;
+  const long long amax = bl * g.Lin + (long long)(ml - bl * nj) * g.sj;
+  const int R = (int)(amax - amin) + bmax - bmin + 1;  // <= RMAX (checked on the host)
+  const long long gbase = amin + bmin;
+  const long long kb_stride = (long long)g.N * SBK;
+  const long long tap_stride = kb_stride * sa.KB;
+  const int ns = ntaps * sa.KB;
+  const int SR = (((RMAX + ntaps - 1) / ntaps) + 7) & ~7;  // image rows per slice (<= STG, checked on the host); ntaps slices cover RMAX
+
+  if (tid >= NCT) {
+    // ================================================================== loader waves (LDS-DMA only)
+    const int ptid = tid - NCT;
+    const int pw = __builtin_amdgcn_readfirstlane(ptid >> 6), lane = ptid & 63;
+    // weight DMA: wave-instruction i of this wave fills LDS bytes [(NPW i + pw) KiB, +1 KiB) of the stage: chunk q = 64 (NPW i + pw) + lane
+    long long b_src[BPW];
+    bool b_ok[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+      const int q = 64 * (NPW * i + pw) + lane;
+      const int piece = q / (BN * 4), rem = q - piece * (BN * 4);
+      const int row = rem >> 2, slot = rem & 3;
+      b_ok[i] = n0 + row < g.N;
+      b_src[i] = (long long)piece * sa.w_piece_stride + (long long)(n0 + row) * SBK + ((slot ^ swz16(row)) << 3);
+    }
+    auto dma_b = [&](int tap, int kb, int buf) {
+      const unsigned short* wt = sa.Wp + (long long)(tw0 + tap * tws) * tap_stride + (long long)kb * kb_stride;
+#pragma unroll
+      for (int i = 0; i < BPW; ++i) {
+        const unsigned short* src = b_ok[i] ? wt + b_src[i] : halo_zero_chunk;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(bbase + buf * B_STAGE + (NPW * i + pw) * 1024), 16, 0, 0);
+      }
+    };
+    // raw activation rows: a wave-instruction carries 8 rows x 128 bytes (lane -> row lane / 8, channels 4 (lane % 8) ..+3), linear in LDS
+    const int lrow = lane >> 3, lch = (lane & 7) * 4;
+    const long long rlo_ll = -gbase, rhi_ll = sa.rowsA - gbase;
+    const int row_lo = rlo_ll > 0 ? (int)(rlo_ll < RMAX ? rlo_ll : RMAX) : 0;          // image rows [row_lo, row_hi) exist in A
+    const int row_hi = rhi_ll < R ? (int)(rhi_ll > 0 ? rhi_ll : 0) : R;
+    const float* const a_lane = g.A + (gbase + lrow) * (long long)g.ldA + lch;
+    // rows [r0, r0 + 8 n) of channel block kb -> dst (n wave-instructions split over the loader waves); returns this wave's count
+    auto dma_rows = [&](int r0, int n, int kb, unsigned char* dst) -> int {
+      const bool ch_ok = kb * SBK + lch < g.Kc;
+      const float* base = a_lane + kb * SBK;
+      int cnt = 0;
+      for (int j = pw; j < n; j += NPW) {
+        const int r = r0 + 8 * j + lrow;
+        const bool ok = ch_ok && r >= row_lo && r < row_hi;
+        const float* src = ok ? base + (long long)(r0 + 8 * j) * g.ldA : halo_zero_f32;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(dst + j * 1024), 16, 0, 0);
+        ++cnt;
+      }
+      return cnt;
+    };
+    // what stage c = (kq, tq) needs: its weight tile (buffer c % 3) and the raw slice the consumers convert during it -- slice tq of
+    // block kq+1 (staging slot c % 3); returns this wave's number of wave-instructions
+    int tq = 0, kq = 0;
+    auto request = [&](int c) -> int {
+      if (c >= ns) return 0;
+      dma_b(tq, kq, c % NB);
+      int n = BPW;
+      if (kq + 1 < sa.KB) n += dma_rows(tq * SR, SR / 8, kq + 1, sbase + (c % 3) * STG_BYTES);
+      if (++tq == ntaps) { tq = 0; ++kq; }
+      return n;
+    };
+    // prologue: the raw image of block 0 whole (into image buffer 1), then the requests of stages 0 and 1
+    if (ns > 0) dma_rows(0, RMAX / 8, 0, smem + A_IMG);
+    request(0);
+    request(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bare_barrier();  // A: raw image of block 0 landed
+    bare_barrier();  // B: the consumers converted it
+    for (int s = 0; s < ns; ++s) {
+      const int n = request(s + 2);
+      // everything older than THIS interval's requests has landed: what stage s+1 needs
+      wait_vmcnt_rt<0, BPW + SPW>(n);
+      bare_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // ==================================================================== consumer waves
+  if (tid < BM) {
+    const long long m = m0 + tid;
+    long long off = -1;
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      off = (b * g.Lout + (phase + g.n_phase * j)) * (long long)g.ldC;
+    }
+    rowoff[tid] = off;
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave / WC, wc = wave % WC;
+  const int l16 = lane & 15, ch = lane >> 4;  // fragment row within a 16-row block, 16-byte chunk (8 k) of the 32-deep stage
+  int ro[MB], jj[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const long long m = m0 + wr * WM + mb * 16 + l16;
+    if (m < Mp) {
+      const long long b = m / nj;
+      const int j = (int)(m - b * nj);
+      ro[mb] = (int)(b * g.Lin + (long long)j * g.sj - amin) - bmin;
+      jj[mb] = j * g.sj;
+    } else {
+      ro[mb] = -bmin;
+      jj[mb] = -(1 << 28);
+    }
+  }
+  int b_off0[NBK];
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) {
+    const int row = wc * WN + nb * 16 + l16;
+    b_off0[nb] = 2 * A_IMG + row * ROWB + ((ch ^ swz16(row)) << 4);
+  }
+  f32x4v acc[MB][NBK];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NBK; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  // raw fp32 rows [r0, r0 + nrows) at `raw` (128 bytes per row) -> piece planes of image `img`: item idx = tid + NCT i covers
+  // channels 4 (idx % 8) ..+3 of row idx / 8
+  const int cchunk = tid & 7;
+  auto convert = [&](const unsigned char* raw, int r0, int nrows, unsigned char* img, int iters) {
+    for (int i = 0; i < iters; ++i) {
+      const int rl = (tid >> 3) + (NCT / 8) * i;
+      const int r = r0 + rl;
+      if (rl < nrows && r < RMAX) {
+        const float4 v = *reinterpret_cast<const float4*>(raw + rl * RAWB + cchunk * 16);
+        uint2 pc[P];
+        split4x<P, H>(v, pc);
+        const int off = r * ROWB + (((cchunk >> 1) ^ swz16(r)) << 4) + ((cchunk & 1) << 3);
+#pragma unroll
+        for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(img + p * A_PIECE + off) = pc[p];
+      }
+    }
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // rowoff
+  bare_barrier();  // A
+  if (ns > 0) convert(smem + A_IMG, 0, RMAX, smem, (RMAX * 8 + NCT - 1) / NCT);
+  if (tid < 4 * P) *reinterpret_cast<uint4*>(smem + (tid >> 2) * A_PIECE + ZROW + (tid & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  bare_barrier();  // B
+  // (the zero row of image buffer 1, where the raw image of block 0 sat until now: complete at the first stage barrier, read from block 1 on)
+  if (tid < 4 * P) *reinterpret_cast<uint4*>(smem + A_IMG + (tid >> 2) * A_PIECE + ZROW + (tid & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  {
+    uint4 av[MB][P], bv[NBK][P];
+    int tap = 0, kb = 0;
+    int tb = 0;
+    int a_off[MB], b_off[NBK];
+    // the slice converted in interval s = (kb, tap): slice `tap` of block kb+1, from staging slot s % 3.  Two steps so that the raw
+    // read has a k-step of matrix work to land behind: raw_read(s) next to the operand fetches, raw_write() after the multiply
+    float4 rawv[CPT];
+    auto raw_read = [&](int s) {
+      if (kb + 1 >= sa.KB) return;
+      const unsigned char* raw = sbase + (s % 3) * STG_BYTES;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int rl = (tid >> 3) + (NCT / 8) * i;
+        if (rl < SR) rawv[i] = *reinterpret_cast<const float4*>(raw + rl * RAWB + cchunk * 16);
+      }
+    };
+    auto raw_write = [&]() {
+      if (kb + 1 >= sa.KB) return;
+      unsigned char* dst = smem + ((kb + 1) & 1) * A_IMG;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int rl = (tid >> 3) + (NCT / 8) * i;
+        const int r = tap * SR + rl;
+        if (rl < SR && r < RMAX) {
+          uint2 pc[P];
+          split4x<P, H>(rawv[i], pc);
+          const int off = r * ROWB + (((cchunk >> 1) ^ swz16(r)) << 4) + ((cchunk & 1) << 3);
+#pragma unroll
+          for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(dst + p * A_PIECE + off) = pc[p];
+        }
+      }
+    };
+    // operand addresses of stage s.  An output row whose tap falls into the conv padding reads the image's zero row
+    auto begin_stage = [&](int s) {
+      tb = tb0 + tap * tbs;
+      const int img_off = (kb & 1) * A_IMG, bst_off = (s % NB) * B_STAGE;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int arow = ro[mb] + tb;
+        const bool valid = (unsigned)(jj[mb] + tb) < (unsigned)g.Lin;
+        a_off[mb] = img_off + (valid ? arow * ROWB + ((ch ^ swz16(arow)) << 4) : ZROW);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) b_off[nb] = b_off0[nb] + bst_off;
+    };
+    auto end_stage = [&]() { if (++tap == ntaps) { tap = 0; ++kb; } };
+    auto fetch = [&]() {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int p = 0; p < P; ++p) av[mb][p] = *reinterpret_cast<const uint4*>(smem + a_off[mb] + p * A_PIECE);
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+        for (int p = 0; p < P; ++p) bv[nb][p] = *reinterpret_cast<const uint4*>(smem + b_off[nb] + p * B_PIECE);
+    };
+    auto mma = [&]() {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) acc[mb][nb] = mfma16_split2x<H>(av[mb], bv[nb], acc[mb][nb]);
+    };
+    // One MFMA spans the whole 32-deep stage, so a wave fetches a stage's operands and then multiplies them; the two waves of a SIMD
+    // run half a stage apart (waves 0-3: fetch(s) | multiply(s) | barrier; waves 4-7: multiply(s-1) | fetch(s) | barrier), so that
+    // one fetches while its partner multiplies.
+    if (wave < 4) {
+      for (int s = 0; s < ns; ++s) {
+        begin_stage(s);
+        fetch();
+        raw_read(s);
+        mma();
+        raw_write();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bare_barrier();
+        end_stage();
+      }
+    } else {
+      for (int s = 0; s < ns; ++s) {
+        raw_read(s);
+        if (s > 0) mma();
+        begin_stage(s);
+        fetch();
+        raw_write();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bare_barrier();
+        end_stage();
+      }
+      if (ns > 0) mma();
+    }
+  }
+  tile_epilogue16<MB, NBK, WM, WN, WR, BN>(g, acc, rowoff, n0, wr, wc, lane, reinterpret_cast<float*>(smem), tid, NCT, H ? F16_OSCALE : 1.f,
+                                           tile_x, tile_y);
+}
+
 int launch_wgrad_taps(const WgradTapsArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int trans_out, int m16) {
   const dim3 block(512);
 #define SVAE_WT(BM_, BN_, T_, S_) do {                                                                                     \
@@ -2644,7 +3039,7 @@ static int launch_halo_ws_fat(const SplitGatherArgs& sa, dim3 grid, hipStream_t 
 }
 
 // V = 16 / 17: gather_halo_ws4_bf16s_kernel (8 consumer + 4 loader waves, 256-row tiles; row field of the code: 128) with / without
-// the quarter-stage stagger of the consumers' second half.  Two pieces (bf16 or fp16) only.  The raw staging ring holds
+// the quarter-stage stagger of the consumers' second half;  V = 18: the same kernel on v_mfma_f32_16x16x32 (gather_halo_ws4m_bf16s_kernel).  Two pieces (bf16 or fp16) only.  The raw staging ring holds
 // three slices of ceil(image rows / ntaps) rows: 88 rows beside 264-row images (ntaps >= 3), 64 beside 320-row images (ntaps >= 5).
 static int ws4_slice_rows(const GatherArgs& g, int rmax) {
   int worst = 0;
@@ -2655,7 +3050,7 @@ static int ws4_slice_rows(const GatherArgs& g, int rmax) {
   }
   return worst;
 }
-template <int BN, bool STAG>
+template <int BN, bool STAG, bool M16 = false>
 static int launch_halo_ws4(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
   const dim3 block(768);
   if (pieces != 2 && pieces != SVAE_PIECES_F16X2) { set_error("split gather: the 12-wave halo kernel is built for 2 pieces"); return SVAE_ERR_SHAPE; }
@@ -2664,7 +3059,11 @@ static int launch_halo_ws4(const SplitGatherArgs& sa, dim3 grid, hipStream_t st,
     set_error("split gather: 256-row halo image of %d rows / its raw slices do not fit", rows);
     return SVAE_ERR_SHAPE;
   }
-#define SVAE_HW4(R_, S_, H_) hipLaunchKernelGGL((gather_halo_ws4_bf16s_kernel<256, BN, R_, S_, H_, STAG>), grid, block, 0, st, sa)
+#define SVAE_HW4(R_, S_, H_)                                                                                         \
+  do {                                                                                                               \
+    if constexpr (M16) hipLaunchKernelGGL((gather_halo_ws4m_bf16s_kernel<256, BN, R_, S_, H_>), grid, block, 0, st, sa); \
+    else hipLaunchKernelGGL((gather_halo_ws4_bf16s_kernel<256, BN, R_, S_, H_, STAG>), grid, block, 0, st, sa);       \
+  } while (0)
   if (pieces == 2) { if (rmax == 264) SVAE_HW4(264, 88, false); else SVAE_HW4(320, 64, false); }
   else { if (rmax == 264) SVAE_HW4(264, 88, true); else SVAE_HW4(320, 64, true); }
 #undef SVAE_HW4
@@ -2709,7 +3108,7 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
     return check_launch("gather_halo_ws_bf16s<dbg>");
   }
 #endif
-  if (v == 16 || v == 17) {
+  if (v == 16 || v == 17 || v == 18) {
     if (t.bm != 128 || (t.bn != 128 && t.bn != 64)) { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_SHAPE; }
     for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + 255) / 256);
     const int nb = g.blocks_m[0] + g.blocks_m[1];
@@ -2719,6 +3118,7 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
     if (!plan_is_affine(g)) { set_error("split gather: tap tables are not arithmetic progressions"); return SVAE_ERR_SHAPE; }
     int e;
     if (v == 16) e = t.bn == 128 ? launch_halo_ws4<128, true>(sa, gridw, st, pieces, rows) : launch_halo_ws4<64, true>(sa, gridw, st, pieces, rows);
+    else if (v == 18) e = t.bn == 128 ? launch_halo_ws4<128, true, true>(sa, gridw, st, pieces, rows) : launch_halo_ws4<64, true, true>(sa, gridw, st, pieces, rows);
     else e = t.bn == 128 ? launch_halo_ws4<128, false>(sa, gridw, st, pieces, rows) : launch_halo_ws4<64, false>(sa, gridw, st, pieces, rows);
     if (e) return e;
     return check_launch("gather_halo_ws4_bf16s");
@@ -2915,7 +3315,7 @@ extern "C" int svae_conv_split_tile(const svae_conv_desc* d, int kind, int* bm, 
   if (t.dma == 11) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 264 ? 264 : 320; }
   if (t.dma == 13) { *bm = 256; *rmax = 264; }
   if (t.dma == 14 || t.dma == 15) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 264 ? 264 : 320; }
-  if (t.dma == 16 || t.dma == 17) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 264 ? 264 : 320; }
+  if (t.dma >= 16 && t.dma <= 18) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 264 ? 264 : 320; }
   return SVAE_OK;
 }
 

@@ -155,7 +155,7 @@ _SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2
                        + (9128128, 9128064)  # 9: halo kernel on 256-row tiles (the row field of the code stays 128)
                        + (10128128, 10128064, 11128128, 11128064)  # 10 / 11: wave-specialised halo kernel, 128- / 256-row tiles
                        + (12128128, 12128064, 13128128, 13128064)  # 12 / 13: the same with three weight-tile buffers
-                       + (16128128, 16128064, 17128128, 17128064))  # 16 / 17: 8 consumer + 4 DMA-only loader waves, 256-row tiles, consumers staggered / not
+                       + (16128128, 16128064, 17128128, 17128064, 18128128, 18128064))  # 18: as 16 on the 16x16x32 MFMA; 16 / 17: 8 consumer + 4 DMA-only loader waves, 256-row tiles, consumers staggered / not
 # (codes 14128128 / 15128128 -- four consumer waves with 128 x 64 wave tiles, compiler-scheduled / pinned pipeline -- exist and are
 #  parity-tested but measured 0-15 % slower than 11 / 13 on every benchmark layer: not tuning candidates)
 _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2, 1"}
@@ -354,6 +354,8 @@ class Conv:
                 elif v in (16, 17):
                     names[kind] = (f"gather_halo_ws4_bf16s_kernel<{bm.value}, {bn.value}, {rm.value}, {88 if rm.value == 264 else 64}, {H}, "
                                    f"{'true' if v == 16 else 'false'}, 0>")
+                elif v == 18:
+                    names[kind] = f"gather_halo_ws4m_bf16s_kernel<{bm.value}, {bn.value}, {rm.value}, {88 if rm.value == 264 else 64}, {H}>"
                 elif v in (14, 15):
                     names[kind] = f"gather_halo_ws_bf16s_kernel<{bm.value}, {bn.value}, {P}, 2, 2, {rm.value}, 0, {'true' if v == 15 else 'false'}, 3, {H}>"
                 elif v >= 4:
