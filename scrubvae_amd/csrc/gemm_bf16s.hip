@@ -2425,7 +2425,7 @@ __global__ __launch_bounds__(512) void wgrad_taps16_bf16s_kernel(const WgradTaps
 
 // ------------------------------------------- the 12-wave halo kernel on v_mfma_f32_16x16x32 (tile code 18)
 // Same structure as gather_halo_ws4_bf16s_kernel (loaders, staging ring, consumer-side conversion, zero-row reads); the matrix work
-// runs on the 16x16x32 shape, which holds a higher clock at equal cycles per FLOP where the chip is power-limited.
+// runs on the 16x16x32 shape: 3-11 % faster alone on the deep layers, no change of the whole step.
 // Fragment = 16 rows x 32 k: lane l reads the 16-byte chunk l / 16 of row l % 16 -- one ds_read_b128 per 16-row block, piece and stage.
 // The chunk swizzle differs from swz(): with chunks 0 / 1 of rows 0-3 / 4-11 / 12-15 in one ds_read_b128 lane group, the map
 // row / 4 -> (0, 3, 2, 1) keeps the 16 lanes of a group on 16 different 16-byte slots.
