@@ -392,6 +392,22 @@ int svae_clip_grads(float* g, long long n, const float* sumsq, float max_norm, v
  * [n][nrhs], strides in elements between systems; diag may be NULL; n, nrhs <= 64.  LU with partial pivoting, fp32. */
 int svae_small_solve(const float* A, long long strideA, const float* diag, const float* B, long long strideB, float* X,
                      long long strideX, int n, int nrhs, int batch, void* stream);
+/* Gaussian log-likelihoods of the streaming quadratic discriminants (reference: QuadraticDiscriminantFilter.cgll,
+ * src/scrubvae/model/disentangle.py:129-134 -- torch.linalg.solve + torch.logdet per (mean, covariance) pair, 4 pairs per class
+ * and step, evaluate_loss :186-232).  x [batch][ldx] (first n columns), mean [pairs][n], S [pairs][n][n] row-major, n <= 64:
+ *   ll[p][b] = -0.5 (logdet S_p + r^T S_p^-1 r),  r = x_b - mean_p   (NaN for det < 0, +inf for a singular S, as torch.logdet gives)
+ *   grad[p][b][:] = d ll[p][b] / d x_b = -0.5 (S_p^-1 + S_p^-T) r     (grad may be NULL) */
+int svae_gauss_ll(const float* x, int ldx, const float* mean, const float* S, float* ll, float* grad, int batch, int n, int pairs,
+                  void* stream);
+/* Kernel-density mutual information between latent means and conditioning variables (reference: MutInfoEstimator.forward,
+ * src/scrubvae/model/disentangle.py:278-317; loss `mcmi`, src/scrubvae/train/losses.py:221-225).  x [batch][ldx] (zx columns),
+ * y [batch][ldy] (dy columns), centres xs [centres][zx], ys [centres][dy]; var: one value (var_per_centre = 0, "sphere",
+ * logAx[1]) or [centres][zx] ("diagonal", logAx[centres]); zx, dy <= 64.
+ *   val[b] = lse_s a_s - lse_s b_s - lse_s c_s  (the reference's three un-normalised log-sum-exps; the loss is mean_b val[b])
+ *   grad[b][:] = d val[b] / d x_b               (grad may be NULL) */
+int svae_kde_mi(const float* x, int ldx, const float* y, int ldy, const float* xs, const float* ys, const float* var,
+                int var_per_centre, const float* logAx, float logAy, float gamma, float* val, float* grad, int batch, int centres,
+                int zx, int dy, void* stream);
 /* sum of squares partials for clip_grad_norm_ (trainer.py:164): part[svae_sumsq_blocks(n)] */
 int svae_sumsq_blocks(long long n);
 int svae_sumsq_partial(const float* x, long long n, float* part, void* stream);

@@ -138,6 +138,8 @@ SIGNATURES = {
     "svae_adam_advance": (I, [P, F, F, P]),
     "svae_clip_grads": (I, [P, LL, P, F, P]),
     "svae_small_solve": (I, [P, LL, P, P, LL, P, LL, I, I, I, P]),
+    "svae_gauss_ll": (I, [P, I, P, P, P, P, I, I, I, P]),
+    "svae_kde_mi": (I, [P, I, P, I, P, P, P, I, P, F, F, P, P, I, I, I, I, P]),
     "svae_sumsq_blocks": (I, [LL]),
     "svae_sumsq_partial": (I, [P, LL, P, P]),
     "svae_reduce_rows": (I, [P, I, I, F, P, I, P]),

@@ -345,3 +345,231 @@ extern "C" int svae_small_solve(const float* A, long long strideA, const float* 
   hipLaunchKernelGGL(small_solve_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, A, strideA, diag, B, strideB, X, strideX, n, nrhs);
   return check_launch("small_solve");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Gaussian log-likelihoods of the streaming quadratic discriminants (reference: QuadraticDiscriminantFilter.cgll,
+// disentangle.py:129-134: -0.5 (logdet S + r^T S^-1 r), r = x - m, evaluated 4 x per class and step through
+// torch.linalg.solve / torch.logdet).  One launch for all (mean, covariance) pairs: grid (sample tiles, pairs); every workgroup
+// inverts ITS pair's S in LDS ([S | I], Gauss-Jordan with partial pivoting: n <= 64, a few thousand operations) and its 256 threads
+// then own one sample each: y1 = S^-1 r, y2 = S^-T r, ll = -0.5 (logdet + r . y1), and -- what the backward pass needs --
+// the gradient field d ll / d x = -0.5 (y1 + y2).  logdet follows torch.logdet: NaN for a negative determinant, -inf for a
+// singular matrix.
+template <int NT>
+__global__ __launch_bounds__(256) void gauss_ll_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                        const float* __restrict__ S, float* __restrict__ ll, float* __restrict__ grad,
+                                                        int batch, int n) {
+  __shared__ float M[SOLVE_MAXN][2 * SOLVE_MAXN + 1];
+  __shared__ int piv;
+  __shared__ float logdet_s;
+  const int tid = threadIdx.x, w = 2 * n, pair = blockIdx.y;
+  const float* a = S + (long long)pair * n * n;
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, j = e - i * n;
+    M[i][j] = a[e];
+    M[i][n + j] = i == j ? 1.f : 0.f;
+  }
+  float logdet = 0.f;
+  int neg = 0;
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    if (tid < 64) {
+      float v = (tid >= k && tid < n) ? fabsf(M[tid][k]) : -1.f;
+      int idx = tid;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+      }
+      if (tid == 0) piv = idx;
+    }
+    __syncthreads();
+    const int p = piv;
+    if (p != k) {
+      neg ^= 1;
+      for (int j = tid; j < w; j += 256) { const float t = M[k][j]; M[k][j] = M[p][j]; M[p][j] = t; }
+    }
+    __syncthreads();
+    const float pv = M[k][k];
+    logdet += logf(fabsf(pv));  // log(0) = -inf, as torch.logdet of a singular matrix
+    neg ^= pv < 0.f;
+    const float inv = 1.f / pv;
+    // Gauss-Jordan: every row i != k loses its column-k entry (columns > k only: the others are final or unused)
+    const int cols = w - k - 1;
+    for (int e = tid; e < (n - 1) * cols; e += 256) {
+      int i = e / cols;
+      i += i >= k;
+      const int j = k + 1 + e % cols;
+      M[i][j] -= (M[i][k] * inv) * M[k][j];
+    }
+    __syncthreads();
+    for (int j = k + 1 + tid; j < w; j += 256) M[k][j] *= inv;  // row k normalised; its rows-i updates above used the old row through `inv`
+    __syncthreads();
+  }
+  if (tid == 0) logdet_s = neg ? __builtin_nanf("") : logdet;
+  __syncthreads();
+  // M[:, n:] = S^-1.  One sample per thread, its residual in registers (NT = 32 or 64 >= n, loops unrolled over NT)
+  const int b = blockIdx.x * 256 + tid;
+  const bool live = b < batch;
+  const float* xb = x + (long long)(live ? b : 0) * ldx;
+  const float* mp = mean + (long long)pair * n;
+  float r[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) r[j] = j < n ? xb[j] - mp[j] : 0.f;
+  float quad = 0.f;
+  for (int i = 0; i < n; ++i) {  // y1[i] = sum_j Sinv[i][j] r[j];  y2[i] = sum_j Sinv[j][i] r[j]  (LDS broadcasts)
+    float y1 = 0.f, y2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (j < n) {
+        y1 += M[i][n + j] * r[j];
+        y2 += M[j][n + i] * r[j];
+      }
+    }
+    quad += (xb[i] - mp[i]) * y1;
+    if (grad && live) grad[((long long)pair * batch + b) * n + i] = -0.5f * (y1 + y2);
+  }
+  if (live) ll[(long long)pair * batch + b] = -0.5f * (logdet_s + quad);
+}
+
+extern "C" int svae_gauss_ll(const float* x, int ldx, const float* mean, const float* S, float* ll, float* grad, int batch, int n,
+                             int pairs, void* stream) {
+  SVAE_REQUIRE(x && mean && S && ll && batch >= 1 && pairs >= 1 && n >= 1 && n <= SOLVE_MAXN && ldx >= n, SVAE_ERR_ARG,
+               "gauss_ll: n <= %d", SOLVE_MAXN);
+  const dim3 grid((batch + 255) / 256, pairs);
+  if (n <= 32) hipLaunchKernelGGL(gauss_ll_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, mean, S, ll, grad, batch, n);
+  else hipLaunchKernelGGL(gauss_ll_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, mean, S, ll, grad, batch, n);
+  return check_launch("gauss_ll");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Kernel-density mutual information between the latent means and the conditioning variables (reference: MutInfoEstimator.forward,
+// disentangle.py:278-317; loss key `mcmi`, losses.py:221-225).  Per sample b and mixture centre s:
+//   a_s = -0.5 (logA_x[s] + logA_y + |x_b - x_s|^2 / var_s + |y_b - y_s|^2 / gamma),  b_s = -0.5 (logA_x[s] + |x_b - x_s|^2 / var_s),
+//   c_s = -0.5 (logA_y + |y_b - y_s|^2 / gamma);   val_b = lse_s a_s - lse_s b_s - lse_s c_s   (the reference's un-normalised sums)
+// and the gradient the encoder is seeded with, d val_b / d x_b = sum_s (softmax(a)_s - softmax(b)_s) (x_s - x_b) / var_s.
+// The reference materialises [B, S, z] difference tensors; here a workgroup owns 16 samples, 16 lanes per sample share the centres
+// of a 64-centre LDS tile, pass 1 keeps running (max, sum) pairs of the three log-sum-exps, pass 2 re-evaluates the exponents against
+// the final values and accumulates the gradient in registers.  var: one value ("sphere") or [S][zx] ("diagonal").
+constexpr int KDE_TS = 64;
+template <int ZT>
+__global__ __launch_bounds__(256) void kde_mi_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy,
+                                                      const float* __restrict__ xs, const float* __restrict__ ys,
+                                                      const float* __restrict__ var, int var_per_centre, const float* __restrict__ logAx,
+                                                      float logAy, float gamma, float* __restrict__ val, float* __restrict__ grad,
+                                                      int batch, int S, int zx, int dy) {
+  __shared__ float xs_t[KDE_TS][ZT + 1], iv_t[KDE_TS][ZT + 1], ys_t[KDE_TS][SOLVE_MAXN + 1], la_t[KDE_TS];
+  __shared__ float ysam[16][SOLVE_MAXN + 1];
+  const int tid = threadIdx.x, sb = tid >> 4, l = tid & 15;
+  const int b = blockIdx.x * 16 + sb;
+  const bool live = b < batch;
+  const float* xb = x + (long long)(live ? b : 0) * ldx;
+  float xr[ZT];
+#pragma unroll
+  for (int d = 0; d < ZT; ++d) xr[d] = d < zx ? xb[d] : 0.f;
+  for (int e = tid; e < 16 * dy; e += 256) {
+    const int i = e / dy, j = e - i * dy;
+    const int bb = blockIdx.x * 16 + i;
+    ysam[i][j] = bb < batch ? y[(long long)bb * ldy + j] : 0.f;
+  }
+  const float ig = 1.f / gamma;
+  auto load_tile = [&](int s0) {
+    __syncthreads();  // the previous tile is consumed
+    for (int e = tid; e < KDE_TS * zx; e += 256) {
+      const int i = e / zx, j = e - i * zx;
+      const int s = s0 + i;
+      xs_t[i][j] = s < S ? xs[(long long)s * zx + j] : 0.f;
+      iv_t[i][j] = 1.f / (var_per_centre ? (s < S ? var[(long long)s * zx + j] : 1.f) : var[0]);
+    }
+    for (int e = tid; e < KDE_TS * dy; e += 256) {
+      const int i = e / dy, j = e - i * dy;
+      ys_t[i][j] = s0 + i < S ? ys[(long long)(s0 + i) * dy + j] : 0.f;
+    }
+    if (tid < KDE_TS) la_t[tid] = var_per_centre ? (s0 + tid < S ? logAx[s0 + tid] : 0.f) : logAx[0];
+    __syncthreads();
+  };
+  auto exponents = [&](int i, float& sdx, float& sdy) {
+    sdx = 0.f;
+#pragma unroll
+    for (int d = 0; d < ZT; ++d)
+      if (d < zx) { const float df = xr[d] - xs_t[i][d]; sdx += df * iv_t[i][d] * df; }
+    sdy = 0.f;
+    for (int e = 0; e < dy; ++e) { const float df = ysam[sb][e] - ys_t[i][e]; sdy += df * ig * df; }
+  };
+  // pass 1: running (max, sum) of the three log-sum-exps over this lane's centres
+  float ma = -INFINITY, mb = -INFINITY, mc = -INFINITY, sa = 0.f, sbb = 0.f, sc = 0.f;
+  auto push = [](float v, float& m, float& sum) {
+    if (v > m) { sum = sum * expf(m - v) + 1.f; m = v; }
+    else sum += expf(v - m);
+  };
+  for (int s0 = 0; s0 < S; s0 += KDE_TS) {
+    load_tile(s0);
+#pragma unroll
+    for (int q = 0; q < KDE_TS / 16; ++q) {
+      const int i = l + 16 * q;
+      if (s0 + i < S) {
+        float sdx, sdy;
+        exponents(i, sdx, sdy);
+        push(-0.5f * (la_t[i] + logAy + sdx + sdy), ma, sa);
+        push(-0.5f * (la_t[i] + sdx), mb, sbb);
+        push(-0.5f * (logAy + sdy), mc, sc);
+      }
+    }
+  }
+  auto combine = [](float m, float sum) {  // over the 16 lanes of a sample
+    float mt = m;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) mt = fmaxf(mt, __shfl_xor(mt, o, 64));
+    float st = sum > 0.f ? sum * expf(m - mt) : 0.f;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) st += __shfl_xor(st, o, 64);
+    return mt + logf(st);
+  };
+  const float pxy = combine(ma, sa), px = combine(mb, sbb), py = combine(mc, sc);
+  if (live && l == 0) val[b] = pxy - px - py;
+  if (grad == nullptr) return;  // uniform
+  // pass 2: d val / d x = sum_s (exp(a_s - pxy) - exp(b_s - px)) (x_s - x) / var_s
+  float g[ZT];
+#pragma unroll
+  for (int d = 0; d < ZT; ++d) g[d] = 0.f;
+  for (int s0 = 0; s0 < S; s0 += KDE_TS) {
+    load_tile(s0);
+#pragma unroll
+    for (int q = 0; q < KDE_TS / 16; ++q) {
+      const int i = l + 16 * q;
+      if (s0 + i < S) {
+        float sdx, sdy;
+        exponents(i, sdx, sdy);
+        const float cw = expf(-0.5f * (la_t[i] + logAy + sdx + sdy) - pxy) - expf(-0.5f * (la_t[i] + sdx) - px);
+#pragma unroll
+        for (int d = 0; d < ZT; ++d)
+          if (d < zx) g[d] += cw * (xs_t[i][d] - xr[d]) * iv_t[i][d];
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < ZT; ++d) {
+    if (d < zx) {
+      float t = g[d];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
+      if (live && l == 0) grad[(long long)b * zx + d] = t;
+    }
+  }
+}
+
+extern "C" int svae_kde_mi(const float* x, int ldx, const float* y, int ldy, const float* xs, const float* ys, const float* var,
+                           int var_per_centre, const float* logAx, float logAy, float gamma, float* val, float* grad, int batch,
+                           int centres, int zx, int dy, void* stream) {
+  SVAE_REQUIRE(x && y && xs && ys && var && logAx && val && batch >= 1 && centres >= 1 && zx >= 1 && zx <= SOLVE_MAXN && dy >= 1 &&
+                   dy <= SOLVE_MAXN && ldx >= zx && ldy >= dy && gamma > 0.f,
+               SVAE_ERR_ARG, "kde_mi: 1 <= zx, dy <= %d", SOLVE_MAXN);
+  const dim3 grid((batch + 15) / 16);
+  if (zx <= 32)
+    hipLaunchKernelGGL(kde_mi_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, xs, ys, var, var_per_centre, logAx,
+                       logAy, gamma, val, grad, batch, centres, zx, dy);
+  else
+    hipLaunchKernelGGL(kde_mi_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, xs, ys, var, var_per_centre, logAx,
+                       logAy, gamma, val, grad, batch, centres, zx, dy);
+  return check_launch("kde_mi");
+}

@@ -397,9 +397,10 @@ class MutInfoEstimator(nn.Module):
     conditions of the previous batch (trainer.py:184-199): p(x,y) = mean_s N(x; x_s, var_s) N(y; y_s, gamma), and the
     value is mean_b[log p(x_b,y_b) - log p(x_b) - log p(y_b)] with the 1/num_s factors dropped exactly as the reference
     drops them (its log-sum-exps are not normalised).  `var_mode="sphere"`: var_s = bandwidth; `"diagonal"`: var_s =
-    diag(L_s)^2 + bandwidth per centre.  O(B * num_s * (z + D)) on stock torch device ops, evaluated
-    in centre chunks so that the [B, num_s, z] difference tensor of the reference is never materialised whole;
-    train.losses seeds the HIP backward with d mcmi / d mu.  The reference's `device` argument only places its
+    diag(L_s)^2 + bandwidth per centre.  O(B * num_s * (z + D)); on the device one launch of `kde_mi_kernel` (csrc/latent.hip:
+    values and d / d mu per sample, centres staged through LDS tiles -- the [B, num_s, z] difference tensor of the reference never
+    exists); CPU tensors (the CPU test suite) take the chunked torch evaluation below.  train.losses seeds the HIP backward with
+    d mcmi / d mu.  The reference's `device` argument only places its
     constants; here they follow the centres."""
 
     CHUNK = 256
@@ -423,11 +424,15 @@ class MutInfoEstimator(nn.Module):
             raise ValueError(f"var_mode {var_mode!r} (the reference defines 'sphere' and 'diagonal')")
         self.gamma = bandwidth
         self.register_buffer("logA_x", logA_x)
-        self.register_buffer("logA_y", torch.tensor([self.y_dim * (log2pi + math.log(bandwidth))], device=x_s.device,
-                                                    dtype=x_s.dtype))
+        self._logA_y = self.y_dim * (log2pi + math.log(bandwidth))  # host copy of the constant: no device read-back per step
+        self.register_buffer("logA_y", torch.tensor([self._logA_y], device=x_s.device, dtype=x_s.dtype))
 
     def forward(self, x, y):
         y = y.to(x.dtype)
+        if x.is_cuda and self.x_dim <= 64 and self.y_dim <= 64:  # one launch: the three log-sum-exps and d / d x per sample
+            from .. import ops
+            val = ops.kde_mi_autograd(x, y, self.x_s, self.y_s, self.var_s, self.logA_x, float(self._logA_y), self.gamma)
+            return val.mean()
         lse = [[], [], []]
         for s0 in range(0, self.num_s, self.CHUNK):
             s1 = min(s0 + self.CHUNK, self.num_s)
@@ -501,8 +506,9 @@ class MovingAverageFilter(nn.Module):
 
 class QuadraticDiscriminantFilter(nn.Module):
     """Two streaming one-vs-rest quadratic discriminants per class with automatically tuned forgetting factors
-    (reference: disentangle.py:90-232; loss key `<feat>_qda`, losses.py:248-252).  Stock torch device ops behind the
-    reference API (SURVEY 8a row A2).  Single-rank statistics use torch.mean / torch.cov exactly as the reference;
+    (reference: disentangle.py:90-232; loss key `<feat>_qda`, losses.py:248-252).  On the device the 4 x classes Gaussian
+    log-likelihoods and their gradient fields come from one launch of `gauss_ll_kernel` (csrc/latent.hip: in-LDS inversion with
+    partial pivoting per (mean, covariance) pair, one sample per thread); the moment updates are small torch reductions.  Single-rank statistics use torch.mean / torch.cov exactly as the reference;
     under data parallelism the member / non-member moments are summed over the ranks."""
 
     def __init__(self, nx, classes, lamdiff=1e-2, delta=1e-3):
@@ -553,11 +559,21 @@ class QuadraticDiscriminantFilter(nn.Module):
 
     def evaluate_loss(self, x, y, update=True):
         ll_loss = 0
+        ll_all = None
+        if x.is_cuda and x.shape[1] <= 64:  # all 4 x classes log-likelihoods (and their gradient fields) in ONE launch
+            from .. import ops
+            k, nx = len(self.classes), x.shape[1]
+            means = torch.stack([self.m0a, self.m1a, self.m0b, self.m1b])  # [4, k, nx]
+            covs = torch.stack([self.S0a, self.S1a, self.S0b, self.S1b])   # [4, k, nx, nx]
+            ll_all = ops.gauss_ll_autograd(x, means.reshape(4 * k, nx), covs.reshape(4 * k, nx, nx)).view(4, k, -1)
         for i, label in enumerate(self.classes):
             i1 = (y == label).ravel()
             i0 = ~i1
-            lla0, lla1 = self.cgll(x, self.m0a[i: i + 1], self.S0a[i]), self.cgll(x, self.m1a[i: i + 1], self.S1a[i])
-            llb0, llb1 = self.cgll(x, self.m0b[i: i + 1], self.S0b[i]), self.cgll(x, self.m1b[i: i + 1], self.S1b[i])
+            if ll_all is not None:
+                lla0, lla1, llb0, llb1 = ll_all[0, i], ll_all[1, i], ll_all[2, i], ll_all[3, i]
+            else:
+                lla0, lla1 = self.cgll(x, self.m0a[i: i + 1], self.S0a[i]), self.cgll(x, self.m1a[i: i + 1], self.S1a[i])
+                llb0, llb1 = self.cgll(x, self.m0b[i: i + 1], self.S0b[i]), self.cgll(x, self.m1b[i: i + 1], self.S1b[i])
             if update:
                 with torch.no_grad():
                     ll = torch.stack([torch.sum(i0 * lla0 + i1 * lla1), torch.sum(i0 * llb0 + i1 * llb1)])

@@ -721,6 +721,74 @@ def small_solve(A, B, diag=None):
     return X[0] if single else X
 
 
+def gauss_ll(x, mean, S, want_grad=True):
+    """ll [P, B] = -0.5 (logdet S_p + r^T S_p^-1 r), r = x - mean_p, and (want_grad) d ll / d x [P, B, n], for P (mean, covariance)
+    pairs in one launch (csrc/latent.hip gauss_ll_kernel; reference QuadraticDiscriminantFilter.cgll, disentangle.py:129-134)."""
+    x = x.float()
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    mean = mean.reshape(-1, x.shape[1]).contiguous().float()
+    S3 = S.reshape(-1, x.shape[1], x.shape[1]).contiguous().float()
+    P_, B, n = mean.shape[0], x.shape[0], x.shape[1]
+    ll = torch.empty(P_, B, device=x.device)
+    g = torch.empty(P_, B, n, device=x.device) if want_grad else None
+    check(_lib.lib().svae_gauss_ll(_p(x), x.stride(0), _p(mean), _p(S3), _p(ll), _p(g), B, n, P_, _stream()), "gauss_ll")
+    return ll, g
+
+
+class _GaussLL(torch.autograd.Function):
+    """Differentiable in x (the latent means); the streaming means / covariances are buffers."""
+
+    @staticmethod
+    def forward(ctx, x, mean, S):
+        ll, g = gauss_ll(x.detach(), mean, S, want_grad=x.requires_grad)
+        ctx.g = g
+        return ll
+
+    @staticmethod
+    def backward(ctx, dll):
+        return torch.einsum("pb,pbn->bn", dll, ctx.g), None, None
+
+
+def gauss_ll_autograd(x, mean, S):
+    return _GaussLL.apply(x, mean, S)
+
+
+def kde_mi(x, y, xs, ys, var, logAx, logAy, gamma, want_grad=True):
+    """val [B] (per-sample log p(x,y) - log p(x) - log p(y) under the kernel-density mixture) and d val / d x [B, zx] in one launch
+    (csrc/latent.hip kde_mi_kernel; reference MutInfoEstimator.forward, disentangle.py:278-317)."""
+    x, y = x.float(), y.float()
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    if y.stride(-1) != 1:
+        y = y.contiguous()
+    xs, ys, var, logAx = xs.contiguous().float(), ys.contiguous().float(), var.contiguous().float(), logAx.contiguous().float()
+    B, zx, dy, S = x.shape[0], x.shape[1], y.shape[1], xs.shape[0]
+    per_centre = int(var.numel() != 1)
+    assert var.numel() == (S * zx if per_centre else 1) and logAx.numel() == (S if per_centre else 1)
+    val = torch.empty(B, device=x.device)
+    g = torch.empty(B, zx, device=x.device) if want_grad else None
+    check(_lib.lib().svae_kde_mi(_p(x), x.stride(0), _p(y), y.stride(0), _p(xs), _p(ys), _p(var), per_centre, _p(logAx), float(logAy),
+                                 float(gamma), _p(val), _p(g), B, S, zx, dy, _stream()), "kde_mi")
+    return val, g
+
+
+class _KdeMI(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, xs, ys, var, logAx, logAy, gamma):
+        val, g = kde_mi(x.detach(), y, xs, ys, var, logAx, logAy, gamma, want_grad=x.requires_grad)
+        ctx.g = g
+        return val
+
+    @staticmethod
+    def backward(ctx, dval):
+        return (dval[:, None] * ctx.g,) + (None,) * 7
+
+
+def kde_mi_autograd(x, y, xs, ys, var, logAx, logAy, gamma):
+    return _KdeMI.apply(x, y, xs, ys, var, logAx, logAy, gamma)
+
+
 def sumsq_blocks(n):
     return int(_lib.lib().svae_sumsq_blocks(n))
 

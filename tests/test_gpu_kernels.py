@@ -255,6 +255,73 @@ def test_small_solve_vs_fp64(ops, n, nrhs, batch, with_diag):
     assert torch.equal(one, out[0])  # the unbatched call is the same kernel on one system
 
 
+@pytest.mark.parametrize("n,B,pairs", [(32, 300, 8), (5, 37, 3), (40, 257, 2), (64, 64, 1), (1, 10, 2)])
+def test_gauss_ll_vs_fp64(ops, n, B, pairs):
+    """svae_gauss_ll (QuadraticDiscriminantFilter.cgll, reference disentangle.py:129-134: torch.linalg.solve + torch.logdet)
+    against fp64 torch, values and the gradient with respect to x through the autograd wrapper; the last pair is a general
+    (non-symmetric, first pivot zero) matrix so that the row pivoting and the S^-T half of the gradient are exercised."""
+    g = torch.Generator().manual_seed(7 * n + pairs)
+    X = torch.randn(pairs, 4 * n + 8, n, generator=g, dtype=torch.float64)
+    S = X.transpose(1, 2) @ X / (4 * n + 8) + 0.1 * torch.eye(n, dtype=torch.float64)
+    if n > 1:
+        S[-1] = torch.randn(n, n, generator=g, dtype=torch.float64) * 0.3 + torch.eye(n, dtype=torch.float64)
+        S[-1][0, 0] = 0.0
+        if torch.linalg.det(S[-1]) < 0:  # keep the determinant positive: swap two rows
+            S[-1][[1, 2 % n]] = S[-1][[2 % n, 1]]
+    m = torch.randn(pairs, n, generator=g, dtype=torch.float64)
+    x = torch.randn(B, n, generator=g, dtype=torch.float64, requires_grad=True)
+    wts = torch.randn(pairs, B, generator=g, dtype=torch.float64)
+    ref = torch.stack([-0.5 * (torch.logdet(S[p]) + ((x - m[p]) * torch.linalg.solve(S[p], (x - m[p]).T).T).sum(1)) for p in range(pairs)])
+    (ref * wts).sum().backward()
+    xd = x.detach().float().cuda().requires_grad_(True)
+    out = ops.gauss_ll_autograd(xd, m.float().cuda(), S.float().cuda())
+    (out * wts.float().cuda()).sum().backward()
+    assert float((out.detach().double().cpu() - ref.detach()).abs().max() / ref.detach().abs().max()) < 2e-5
+    assert float((xd.grad.double().cpu() - x.grad).abs().max() / x.grad.abs().max()) < 2e-5
+    # a strided view of a wider buffer (mu inside the heads' output) is read in place
+    wide = torch.zeros(B, n + 3, device="cuda")
+    wide[:, :n] = xd.detach()
+    ll2, _ = ops.gauss_ll(wide[:, :n], m.float().cuda(), S.float().cuda(), want_grad=False)
+    assert torch.equal(ll2, out.detach())
+
+
+def test_gauss_ll_degenerate_matrices(ops):
+    """torch.logdet semantics: NaN for a negative determinant, -inf (log-likelihood +inf or NaN) for a singular matrix."""
+    S = torch.stack([torch.diag(torch.tensor([1.0, -2.0, 3.0])), torch.diag(torch.tensor([1.0, 0.0, 3.0])), torch.eye(3)]).cuda()
+    x = torch.randn(5, 3, device="cuda")
+    ll, _ = ops.gauss_ll(x, torch.zeros(3, 3, device="cuda"), S, want_grad=False)
+    assert torch.isnan(ll[0]).all()
+    assert not torch.isfinite(ll[1]).any()
+    ref = -0.5 * (x * x).sum(1)
+    assert float((ll[2] - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("B,S,zx,dy,mode", [(300, 300, 32, 3, "sphere"), (37, 100, 5, 1, "diagonal"), (64, 257, 40, 7, "diagonal"),
+                                            (16, 5, 32, 2, "sphere"), (1, 1, 8, 1, "sphere")])
+def test_kde_mi_vs_fp64(ops, B, S, zx, dy, mode):
+    """svae_kde_mi (MutInfoEstimator.forward, reference disentangle.py:278-317) against the estimator's own chunked torch evaluation
+    in fp64 on the CPU -- the path the reference-generated `mcmi_tiny` fixture pins: the loss and its gradient with respect to the
+    latent means, both variance modes, sizes that are not multiples of the 16-sample / 64-centre tiles."""
+    from scrubvae_amd.model.disentangle import MutInfoEstimator
+    g = torch.Generator().manual_seed(B + S + zx)
+    x_s = torch.randn(S, zx, generator=g, dtype=torch.float64)
+    y_s = torch.randn(S, dy, generator=g, dtype=torch.float64)
+    Ls = torch.diag_embed(torch.rand(S, zx, generator=g, dtype=torch.float64) + 0.2) if mode == "diagonal" else None
+    est = MutInfoEstimator(x_s, y_s, 0.7, var_mode=mode, model_var=Ls)
+    x = (x_s[torch.randint(0, S, (B,), generator=g)] + 0.5 * torch.randn(B, zx, generator=g, dtype=torch.float64)).requires_grad_(True)
+    y = torch.randn(B, dy, generator=g, dtype=torch.float64)
+    ref = est(x, y)
+    ref.backward()
+    est_d = MutInfoEstimator(x_s.float().cuda(), y_s.float().cuda(), 0.7, var_mode=mode, model_var=None if Ls is None else Ls.float().cuda())
+    xd = x.detach().float().cuda().requires_grad_(True)
+    out = est_d(xd, y.float().cuda())
+    out.backward()
+    assert abs(float(out) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+    # the gradient is a difference of two softmax averages of (x_s - x) / var (terms of order 1 / B): with few centres it nearly
+    # cancels, so the floor of the scale is that of a term, not of the result
+    assert float((xd.grad.double().cpu() - x.grad).abs().max()) < 2e-5 * max(float(x.grad.abs().max()), 1.0 / B)
+
+
 def test_heads_diag(ops):
     B, z = 37, 8
     h = torch.randn(B, 2 * z, dtype=torch.float64, requires_grad=True)
