@@ -353,8 +353,8 @@ class LinearProjection(nn.Module):
     """Linear decoder of one feature plus the projection of the latent onto the decoder's null space (reference:
     disentangle.py:717-734; method `linear`, loss key `<feat>_lin`, losses.py:258-265): v = z Wt (+ b),
     z_null = z - (W Wt)^-1 v ... W, i.e. z minus its component in the row space of W.  When the method is configured every
-    other scrubber of that feature reads z_null instead of mu (residual.py:351-355, losses.py:232-235).  A [out x out]
-    solve and two [B x z] products: stock torch device ops; the model keeps the small autograd graph and
+    other scrubber of that feature reads z_null instead of mu (residual.py:351-355, losses.py:232-235).  The [out x out]
+    inverse runs on `small_solve_kernel` (csrc/latent.hip) behind an autograd function, the [B x z] products are library GEMMs; the model keeps the small autograd graph and
     train.losses / the HIP backward differentiate through it to mu and to `decoder.weight`."""
 
     def __init__(self, in_dim, out_dim, bias=False):
@@ -370,7 +370,11 @@ class LinearProjection(nn.Module):
         if self.decoder.has_bias:
             x = x + self.decoder.bias
         nrm = w @ w.T
-        z_null = z - torch.linalg.solve(nrm, x.T).T @ w
+        if nrm.is_cuda and nrm.shape[0] <= 64:  # [out x out] inverse on the batched LU kernel; the [B x out] products are library GEMMs
+            from .. import ops
+            z_null = z - (x @ ops.small_inverse_autograd(nrm).T) @ w
+        else:
+            z_null = z - torch.linalg.solve(nrm, x.T).T @ w
         return {"v": x, "z_null": z_null}
 
 

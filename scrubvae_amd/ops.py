@@ -721,6 +721,26 @@ def small_solve(A, B, diag=None):
     return X[0] if single else X
 
 
+class _SmallInverse(torch.autograd.Function):
+    """A^-1 of one small matrix on the batched LU kernel (right-hand side = identity), differentiable:
+    d A = -A^-T (d A^-1) A^-T."""
+
+    @staticmethod
+    def forward(ctx, A):
+        inv = small_solve(A.detach(), torch.eye(A.shape[0], device=A.device, dtype=torch.float32))
+        ctx.save_for_backward(inv)
+        return inv
+
+    @staticmethod
+    def backward(ctx, dinv):
+        (inv,) = ctx.saved_tensors
+        return -(inv.T @ dinv @ inv.T)
+
+
+def small_inverse_autograd(A):
+    return _SmallInverse.apply(A)
+
+
 def gauss_ll(x, mean, S, want_grad=True):
     """ll [P, B] = -0.5 (logdet S_p + r^T S_p^-1 r), r = x - mean_p, and (want_grad) d ll / d x [P, B, n], for P (mean, covariance)
     pairs in one launch (csrc/latent.hip gauss_ll_kernel; reference QuadraticDiscriminantFilter.cgll, disentangle.py:129-134)."""

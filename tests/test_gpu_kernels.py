@@ -255,6 +255,24 @@ def test_small_solve_vs_fp64(ops, n, nrhs, batch, with_diag):
     assert torch.equal(one, out[0])  # the unbatched call is the same kernel on one system
 
 
+def test_small_inverse_autograd_vs_fp64(ops):
+    """LinearProjection's (W W^T)^-1 (reference disentangle.py:717-734: torch.linalg.solve(nrm, x.T)) through ops.small_inverse_autograd:
+    the value and the gradient with respect to W of the projected latent against fp64 autograd."""
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(3, 16, generator=g, dtype=torch.float64, requires_grad=True)
+    z = torch.randn(50, 16, generator=g, dtype=torch.float64, requires_grad=True)
+    c = torch.randn(50, 16, generator=g, dtype=torch.float64)
+    x = z @ w.T
+    ref = z - torch.linalg.solve(w @ w.T, x.T).T @ w
+    (ref * c).sum().backward()
+    wd, zd = w.detach().float().cuda().requires_grad_(True), z.detach().float().cuda().requires_grad_(True)
+    out = zd - ((zd @ wd.T) @ ops.small_inverse_autograd(wd @ wd.T).T) @ wd
+    (out * c.float().cuda()).sum().backward()
+    assert float((out.detach().double().cpu() - ref.detach()).abs().max()) < 2e-5
+    assert float((wd.grad.double().cpu() - w.grad).abs().max() / w.grad.abs().max()) < 2e-5
+    assert float((zd.grad.double().cpu() - z.grad).abs().max() / z.grad.abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("n,B,pairs", [(32, 300, 8), (5, 37, 3), (40, 257, 2), (64, 64, 1), (1, 10, 2)])
 def test_gauss_ll_vs_fp64(ops, n, B, pairs):
     """svae_gauss_ll (QuadraticDiscriminantFilter.cgll, reference disentangle.py:129-134: torch.linalg.solve + torch.logdet)
