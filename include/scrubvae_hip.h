@@ -99,8 +99,8 @@ int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const float* dy, fl
  * workgroup / LDS buffering, see gemm_bf16s.hip; 16 / 17 / 18 (18: on the 16x16x32 MFMA): the 12-wave halo kernel with DMA-only loader waves, 256-row
  * tiles).  d->tile[2] for the split weight gradient: V*1000000 + BM*1000 + BN with V a bit set -- 1: single LDS buffer,
  * 2: XCD-aware workgroup order, 4: all taps of a tile in one workgroup (contiguous 5 / 6-tap geometries, 2 pieces;
- * SVAE_ERR_SHAPE otherwise), 8: that kernel on the 16x16x32 MFMA shape, 16: (transposed convs) the taps folded into
- * the dY columns -- one column padding for all taps.  Results do not depend on the tile code beyond
+ * SVAE_ERR_SHAPE otherwise), 8: that kernel on the 16x16x32 MFMA shape, 16: the taps folded into the dY columns (transposed
+ * convs) or into the X channel rows (convs) of the tile -- one tile padding for all taps.  Results do not depend on the tile code beyond
  * the summation order (deterministic for a given code). */
 size_t svae_conv_split_bytes(const svae_conv_desc* d);
 int svae_conv_split_weights(const svae_conv_desc* d, const float* w, void* wsplit, void* stream);

@@ -1789,7 +1789,10 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
   // then pad T * c_out to a multiple of BN once instead of c_out per tap (141 -> 256 per tap with BN = 128 is 44 % idle columns,
   // 22 * 144 -> 3200 is 1 %), X is staged once for 128 flat columns instead of once per tap, and a staging thread masks its rows with
   // the tap of ITS channel quad (flat_np is a multiple of 4: a quad never straddles two taps).
-  const int np = g.flat_np;
+  // flat_mp > 0 is the mirror image for (non-transposed) convs, whose dY rows do not depend on the tap: the taps fold into the ROWS
+  // of the weight tile -- channel row m' = t * flat_mp + c_in of a virtual [rows][T * flat_mp] view of X (conv_in: 7 taps x 144
+  // channels = 1008 rows in 8 tiles of 128 instead of 7 x 2 half-empty ones), dY is staged once per 128 flat rows.
+  const int np = g.flat_np, mp = g.flat_mp;
   const int tbx = g.bx[ti], tby = g.by[ti];
 
   // staging unit of this thread: operand (A = X channels, B = dY channels), row group rg, channel quad cq
@@ -1803,8 +1806,14 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
   const int cq = (l16 & 7) + 8 * (q16 % nq8);
   const int rg = ((l16 >> 3) & 1) + 2 * (q16 / nq8);
   int ch0 = (is_a ? c0 : n0) + cq * 4;
-  const bool col_ok = has_unit && ch0 < (is_a ? g.Kc : g.N);
+  bool col_ok = has_unit && ch0 < (is_a ? g.Kc : g.N);
   int tb_unit = is_a ? tbx : tby;          // tap offset of this unit's operand rows
+  if (mp > 0 && is_a) {
+    const int trow = ch0 / mp;             // the tap this X channel quad belongs to (affine tap offsets)
+    tb_unit = g.bx[0] + trow * (g.T > 1 ? g.bx[1] - g.bx[0] : 0);
+    ch0 -= trow * mp;
+    col_ok = has_unit && trow < g.T && ch0 < g.Kc;
+  }
   if (np > 0 && !is_a) {
     const int tcol = ch0 / np;             // the tap this dY channel quad belongs to (affine tap offsets: by[t] = by[0] + t (by[1] - by[0]))
     tb_unit = g.by[0] + tcol * (g.T > 1 ? g.by[1] - g.by[0] : 0);
@@ -1829,12 +1838,14 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
     ptr = base + (b * L + (long long)jj * s + tb) * (long long)ld + (col_ok ? ch0 : 0);
     const long long l = r_end - r;
     left = l > 0x7fffffffLL ? 0x7fffffff : (int)l;
-    xr0 = jj * g.sx + tbx;
+    xr0 = jj * g.sx + (mp > 0 ? (is_a ? tb_unit : 0) : tbx);
     yr0 = jj * g.sy + (np > 0 ? (is_a ? 0 : tb_unit) : tby);  // flat mode: the X rows are shared by columns of different taps: never masked by one
   }
   const int dx16 = r16 * g.sx, dy16 = r16 * g.sy, wrapx = g.nj * g.sx, wrapy = g.nj * g.sy;
   const int yr_base = np > 0 ? (is_a ? 0 : tb_unit) : tby;
-  const bool y_free = np > 0 && is_a;  // (flat mode, X unit: its rows are valid for every tap)
+  const int xr_base = mp > 0 ? (is_a ? tb_unit : 0) : tbx;
+  const bool y_free = np > 0 && is_a;   // (flat columns, X unit: its rows are valid for every tap)
+  const bool x_free = mp > 0 && !is_a;  // (flat rows, dY unit: likewise)
   const int lds_unit = (is_a ? 0 : P * A_PIECE) + lds_row(cq * 4) + rg * 8;
   const float* const zero_row = wgrad_zero_row;
 
@@ -1846,7 +1857,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
     const float* p = ptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = col_ok & (left > i) & ((unsigned)xr < (unsigned)g.Lx) & (((unsigned)yr < (unsigned)g.Ly) | y_free);
+      const bool ok = col_ok & (left > i) & (((unsigned)xr < (unsigned)g.Lx) | x_free) & (((unsigned)yr < (unsigned)g.Ly) | y_free);
       rv[i] = *reinterpret_cast<const float4*>(ok ? p : zero_row);
       ++j;
       p += row_step;
@@ -1855,7 +1866,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
       const bool wrap = j >= g.nj;
       j = wrap ? 0 : j;
       p += wrap ? row_wrap : 0;
-      xr = wrap ? tbx : xr;
+      xr = wrap ? xr_base : xr;
       yr = wrap ? yr_base : yr;
     }
     jj += r16;
@@ -1956,8 +1967,15 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = c0 + wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (c < g.Kc) {
+        int c = c0 + wr * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        bool c_ok = c < g.Kc;
+        if (mp > 0) {  // flat row -> (tap, input channel)
+          const int t = c / mp;
+          c -= t * mp;
+          c_ok = t < g.T && c < g.Kc;
+          out = g.out + (long long)bzi * g.slab_stride + (long long)t * g.Kc * g.ldW;
+        }
+        if (c_ok) {
           float* dst = out + (long long)c * g.ldW + col;
           float v = acc[mt][nt][r];
           if (g.accumulate) v += *dst;

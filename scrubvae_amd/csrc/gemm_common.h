@@ -163,6 +163,7 @@ struct WgradArgs {
   int T, Kc, N, ldX, ldY, ldW, ctiles, bm;
   int accumulate;
   int xmap;  // split-bf16 kernel: XCD-aware workgroup order (tile code variants 2 / 3)
+  int flat_mp;  // split-bf16 kernel, > 0: the taps are folded into the X channels (M = T * flat_mp: convs, dY rows tap-independent; variant bit 16)
   int flat_np;  // split-bf16 kernel, > 0: the taps are folded into the dY columns (N = T * flat_np, variant bit 16; see gemm_bf16s.hip)
 };
 

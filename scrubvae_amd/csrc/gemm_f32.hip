@@ -1078,7 +1078,11 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
     w.ctiles = (d->c_in + 63) / 64;
     tiles = (long long)d->kernel * w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
   }
-  if (flat) tiles = (long long)w.ctiles * (((long long)d->kernel * d->c_out + w.bn - 1) / w.bn);
+  if (flat && d->transposed) tiles = (long long)w.ctiles * (((long long)d->kernel * d->c_out + w.bn - 1) / w.bn);
+  if (flat && !d->transposed) {  // taps folded into the X channel rows
+    w.ctiles = (int)(((long long)d->kernel * ((d->c_in + 3) / 4 * 4) + w.bm - 1) / w.bm);
+    tiles = (long long)w.ctiles * ((d->c_out + w.bn - 1) / w.bn);
+  }
   // resident blocks: 3 per CU for the 128x128 tile (144 VGPR+AGPR), 4 for the smaller ones
   const long long slots = big ? 256 : 256 * ((w.bm == 128 && w.bn == 128) ? 3 : 4);  // 8-wave tiles: one workgroup per CU
   long long want = tiles >= slots ? 1 : slots / tiles;
@@ -1154,11 +1158,18 @@ static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float*
     dim3 grid(wg.ctiles, (a.Cf + wg.bn - 1) / wg.bn, nsplit);
     if (int e = launch_wgrad_taps(a, grid, st, wg.bm, wg.bn, d->transposed ? 1 : 0, (wvariant >> 3) & 1)) return e;
   } else if (pieces > 0 && (wvariant & 16)) {
-    SVAE_REQUIRE(d->transposed && d->kernel >= 2, SVAE_ERR_SHAPE, "conv_wgrad: the flat-tap variant is built for transposed convs (x rows tap-independent)");
-    g.flat_np = d->c_out;
-    g.N = d->kernel * d->c_out;
-    dim3 grid(g.ctiles, (g.N + wg.bn - 1) / wg.bn, nsplit);
-    if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces, wvariant & 3)) return e;
+    SVAE_REQUIRE(d->kernel >= 2 && (d->transposed ? d->c_out % 4 == 0 : (((d->c_in + 3) / 4 * 4) <= d->ld_in)), SVAE_ERR_SHAPE,
+                 "conv_wgrad: the flat-tap variant needs >= 2 taps and a tap's channels in whole quads");
+    if (d->transposed) {  // x rows tap-independent: taps fold into the dY columns
+      g.flat_np = d->c_out;
+      g.N = d->kernel * d->c_out;
+      dim3 grid(g.ctiles, (g.N + wg.bn - 1) / wg.bn, nsplit);
+      if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces, wvariant & 3)) return e;
+    } else {              // dY rows tap-independent: taps fold into the X channel rows (wg.ctiles counts tiles of the flat rows)
+      g.flat_mp = (d->c_in + 3) / 4 * 4;
+      dim3 grid(g.ctiles, (d->c_out + wg.bn - 1) / wg.bn, nsplit);
+      if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces, wvariant & 3)) return e;
+    }
   } else if (pieces > 0) {
     dim3 grid(d->kernel * g.ctiles, (d->c_out + wg.bn - 1) / wg.bn, nsplit);
     if (int e = launch_wgrad_split(g, grid, st, wg.bm, wg.bn, pieces, d->tile[2] / 1000000)) return e;

@@ -166,8 +166,8 @@ _SPLIT_WGRAD_CODES = _TILES + tuple(1000000 + c for c in _TILES) + _WGRAD_BIG + 
 _SPLIT_WGRAD_CODES = _SPLIT_WGRAD_CODES + tuple(2000000 + c for c in _SPLIT_WGRAD_CODES)
 # 4BBBNNN / 6BBBNNN: all taps of a tile in one workgroup (wgrad_taps_bf16s_kernel), launch order / XCD-aware order
 _SPLIT_WGRAD_CODES = _SPLIT_WGRAD_CODES + (4128128, 4064128, 4128064, 6128128, 6064128, 6128064)
-# 16BBBNNN (+1 single buffer, +2 XCD order): transposed convs, the taps folded into the dY columns (one column padding for all taps)
-_SPLIT_WGRAD_CODES = _SPLIT_WGRAD_CODES + (16064128, 16128128, 16128064, 17064128, 18064128, 18128128)
+# 16BBBNNN (+1 single buffer, +2 XCD order): the taps folded into the dY columns (transposed convs) / the X channel rows (convs): one tile padding for all taps
+_SPLIT_WGRAD_CODES = _SPLIT_WGRAD_CODES + (16064128, 16128128, 16128064, 17064128, 18064128, 18128128, 18128064)
 # 12BBBNNN / 14BBBNNN: the all-taps kernel on the 16x16x32 MFMA shape
 _SPLIT_WGRAD_CODES = _SPLIT_WGRAD_CODES + (12128128, 12064128, 12128064, 14128128, 14064128, 14128064)
 # BatchNorm batch statistics (forward) and first-pass backward sums from the conv GEMMs' epilogues where their kernels support it

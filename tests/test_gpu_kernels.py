@@ -600,7 +600,7 @@ def test_split_gather_kernels(ops, case, code, pieces):
                                          (2256256, 2), (3256128, 2), (2128128, 2), (3064064, 2), (2064128, 3),
                                          (4064128, 2), (6064128, 2), (4128064, 2), (6128064, 2), (4128128, 2), (6128128, 2),
                                          (12064128, 2), (14128064, 2), (12128128, 2), (14128128, 2),
-                                         (16064128, 2), (18128128, 2), (17064064, 3), (16128064, 2)])
+                                         (16064128, 2), (18128128, 2), (17064064, 3), (16128064, 2), (18128064, 2)])
 def test_split_wgrad_kernels(ops, case, code, pieces):
     B, L, Cin, Cout, k, s, p, tr = case
     g = torch.Generator().manual_seed(13 + sum(case[:7]))

@@ -7,6 +7,11 @@ B = int(os.environ.get("B", 4096))
 LAYERS = [("enc3.c3", 4, 512, 1024, 5, 1, 2, False), ("dec0.t1", 4, 1024, 512, 5, 1, 2, True), ("enc2.c3", 8, 256, 512, 5, 1, 2, False),
           ("enc1.c3", 16, 128, 256, 5, 1, 2, False), ("enc0.c3", 32, 64, 128, 5, 1, 2, False), ("enc2.c1", 16, 256, 512, 5, 2, 2, False),
           ("dec2.t2", 16, 256, 128, 5, 2, 2, True)]
+if os.environ.get("LAYERS") == "shallow":  # many rows, few channels: conv_in, the 64 / 128-channel blocks, the decoder's last skip conv
+    LAYERS = [("conv_in", 64, 141, 64, 7, 1, 3, False), ("dec3.sk", 50, 128, 64, 6, 1, 2, False), ("dec2.sk", 26, 256, 128, 6, 1, 2, False),
+              ("enc0.c3", 32, 64, 128, 5, 1, 2, False), ("dec3.t1", 25, 128, 64, 5, 1, 2, True), ("dec.out", 49, 64, 141, 22, 1, 3, True)]
+if os.environ.get("LAYERS") == "conv_in":
+    LAYERS = [("conv_in23", 64, 141, 64, 7, 1, 3, False), ("conv_in18", 64, 111, 64, 7, 1, 3, False)]
 codes = [int(c) for c in sys.argv[1:]] or [256256, 2256256]
 COLD = os.environ.get("COLD", "0") != "0"
 _flush = None
