@@ -16,10 +16,14 @@ CrossEntropyLoss to its own softmax output (:304-307).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import ops
 from ..ops import pad16
+
+_TAIL_FORK = os.environ.get("SVAE_TAIL_FORK", "1") != "0"  # env: schedule experiments (0 = the tail stays on the main stream)
 
 SUPPORTED = ("rotation", "prior", "jpe", "root", "total_correlation")
 
@@ -83,20 +87,47 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     root_s = float(loss_scale.get("root", 0.0)) / Bg
     if "jpe" in loss_scale and ("offsets" not in data or "target_pose" not in data):
         raise KeyError("jpe loss needs data['offsets'] and data['target_pose']")
-    _, _, lp, dy = model._run_tail(B, dev_data, jpe_s, root_s, ext_dx6d, train)
-    nb = lp.shape[0]
-    if "jpe" in loss_scale:
-        v = _scalar(model, "jpe")
-        ops.reduce_rows(lp, nb, 2, 1.0 / (Bg * 3 * J), model._buf("tail.sums", (2,)))
-        v.copy_(model._buf("tail.sums", (2,))[0:1])
-        batch_loss["jpe"] = v.view(()).clone()
-        add_total("jpe", v)
-    if "root" in loss_scale:
-        v = _scalar(model, "root")
-        ops.reduce_rows(lp, nb, 2, 1.0 / Bg, model._buf("tail.sums2", (2,)))
-        v.copy_(model._buf("tail.sums2", (2,))[1:2])
-        batch_loss["root"] = v.view(()).clone()
-        add_total("root", v)
+    # The tail kernel is latency-bound (one 6-wave workgroup per CU, ~0.6 ms at B = 4096: DESIGN.md 4) and nothing behind it on the
+    # main chain can start before it ends -- except the scrubbing losses below, which only read the encoder's outputs.  Where the
+    # pass overlaps streams the tail is forked to a side stream (a C-ABI launch; its inputs are prepared here, on the main stream)
+    # and joined after the scrubbing section; the loss terms keep their place in `batch_loss` and in the running total.
+    for k in ("offsets", "target_pose", "root"):
+        if k in dev_data and torch.is_tensor(dev_data[k]):
+            dev_data[k] = model._prep(dev_data[k])
+    tail_out = {}
+
+    def _tail():
+        tail_out["r"] = model._run_tail(B, dev_data, jpe_s, root_s, ext_dx6d, train)
+
+    fork_tail = model._ov and _TAIL_FORK
+    if fork_tail:
+        model._fork(_tail, k=1)
+    else:
+        _tail()
+    for k in ("jpe", "root"):  # placeholders: dict order as the serial schedule writes it
+        if k in loss_scale:
+            batch_loss[k] = None
+
+    def join_tail():
+        model._join_side(1)
+        lp = tail_out["r"][2]
+        nb = lp.shape[0]
+        if "jpe" in loss_scale:
+            v = _scalar(model, "jpe")
+            ops.reduce_rows(lp, nb, 2, 1.0 / (Bg * 3 * J), model._buf("tail.sums", (2,)))
+            v.copy_(model._buf("tail.sums", (2,))[0:1])
+            batch_loss["jpe"] = v.view(()).clone()
+            add_total("jpe", v)
+        if "root" in loss_scale:
+            v = _scalar(model, "root")
+            ops.reduce_rows(lp, nb, 2, 1.0 / Bg, model._buf("tail.sums2", (2,)))
+            v.copy_(model._buf("tail.sums2", (2,))[1:2])
+            batch_loss["root"] = v.view(()).clone()
+            add_total("root", v)
+        return tail_out["r"][3]
+
+    if not fork_tail:  # serial schedule: the terms enter the total in the reference's order
+        dy = join_tail()
 
     # ---- scrubbing losses
     d_mu = model._buf("seed.d_mu", (B, zp), zero=True)
@@ -142,7 +173,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
             if train and sc != 0:
                 d_mu[:, :z] += sc * torch.autograd.grad(val, mu_t)[0]
         else:
-            v.copy_(torch.zeros_like(batch_loss["jpe"]).reshape(1))
+            v.zero_()
         batch_loss["mcmi"] = v.view(()).clone()
         add_total("mcmi", v)
     methods = disentangle_config["method"] if disentangle_config is not None else {}
@@ -337,6 +368,8 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 dlv = model._buf("tc.dlv", (B, z))
                 ops.tc_bwd(zc, zcp, mu_b, zp, lv, B, z, lse_l, lse_a, w, d_mu, zp, dlv, z)
 
+    if fork_tail:
+        dy = join_tail()
     if train:
         model._pending = dict(dy=dy, kl_scale=kl_scale, d_mu=d_mu, scrub=scrub, dsigma=dsigma, dlv=dlv, lin_pgrads=lin_pgrads,
                               accumulate=getattr(model, "accumulate_grads", False))
