@@ -5,7 +5,9 @@ the arithmetic runs in libscrubvae_hip.so through ``EnsembleRunner``: every Line
 MFMA implicit-GEMM kernel (a 1x1 "conv"), ReLU / losses are the HIP row kernels.
 The streaming closed-form scrubbers of SURVEY 8a row A2 (MovingAvgLeastSquares, MovingAverageFilter,
 QuadraticDiscriminantFilter, LinearProjection, MutInfoEstimator) follow below, behind the reference's
-API, on device tensor ops that seed the HIP backward.
+API: their solves, Gaussian log-likelihoods and the kernel-density estimator run on csrc/latent.hip kernels
+(ops.small_solve, ops.gauss_ll_autograd, ops.kde_mi_autograd), the [B x z] Gram products are library GEMMs,
+and every loss seeds the HIP backward.
 """
 from __future__ import annotations
 
@@ -239,8 +241,8 @@ class MovingAvgLeastSquares(nn.Module):
     Two exponentially-forgetting covariance pairs (Sxx, Sxy) with forgetting factors lam0 < lam1 = lam0 + lamdiff;
     forward solves both normal equations and predicts y from the latent means, `evaluate_loss` returns the mean of
     the two squared errors and nudges the forgetting factors toward the better decoder, `update` folds a batch into
-    the covariances.  These are [z x z] solves and [B x z] products on device tensors -- stock torch ops behind the
-    reference API, as SURVEY 8a allows for this row; the gradient into the encoder is seeded analytically by
+    the covariances.  Both [z x z] solves run in one launch of the batched LU kernel (ops.small_solve), the [B x z] products
+    are library GEMMs; the gradient into the encoder is seeded analytically by
     train.losses (the decoders W are constants of the step).  `polynomial_order` p > 1 appends, for every degree
     d = 2..p, the products of all size-d multisets of latent dimensions scaled by nx / (number of such products)
     (disentangle.py:440-464); the seed then also goes through the expansion's Jacobian."""
