@@ -227,6 +227,9 @@ def pmc_traffic(kernel, tag):
 
 def run_workload(args, full, B, rank, world, roofline=True):
     """Times `args.steps` optimizer steps of one workload (after `args.warmup` untimed ones); returns the result fields."""
+    import gc
+    gc.collect()  # the previous workload's model (20 GB of buffers at batch 4096) goes back to the allocator before this one builds
+    torch.cuda.empty_cache()
     from scrubvae_amd import parallel, ops
     from scrubvae_amd.data import synthetic
     from scrubvae_amd.train.losses import get_batch_loss

@@ -49,6 +49,9 @@ def find_out_dim(latent_dim, kernel, num_layers, dilation=None):
     return int(l_out)
 
 
+_SIDE_STREAMS = {}  # device index -> side streams shared by every model of the process (see ResVAE._side_stream)
+
+
 class ResidualBlock(nn.Module):
     """residual.py:71-119: skip Conv1d(s=2) || [Conv1d(s=2) -> BN -> PReLU -> Conv1d] ; add ; BN ; PReLU."""
 
@@ -354,8 +357,14 @@ class ResVAE(nn.Module):
         self._db_batch.add(dy, cv.batch * cv.l_out, cv.c_out_p, cv.desc.ld_out, p.bias.grad)
 
     def _side_stream(self, k=0):
+        """Side stream k of this model's device, from a PROCESS-WIDE pool: the runtime multiplexes streams onto a few hardware
+        queues, and a second model with streams of its own (an evaluation model beside the training model; bench.py's second
+        workload) found two of its three streams on one queue -- the batch-1024 step ran at its serial 5.3 ms instead of 4.9."""
+        pool = _SIDE_STREAMS.setdefault(torch.device(self.device).index or 0, [])
+        while len(pool) <= k:
+            pool.append(torch.cuda.Stream(device=self.device))
         while len(self._sides) <= k:
-            self._sides.append(torch.cuda.Stream(device=self.device))
+            self._sides.append(pool[len(self._sides)])
         return self._sides[k]
 
     def _event(self):
