@@ -864,21 +864,14 @@ class ResVAE(nn.Module):
         anchor = self.flat_params.new_zeros((), requires_grad=True)
         return _TotalLoss.apply(anchor, total, self)
 
-    def backward_from_seeds(self):
-        """Reverse schedule.  Needs the seeds prepared by train.losses.get_batch_loss:
-        pending = {dy [rows,Cp], kl_scale, d_mu [B,zp] or None, scrub: [...]}"""
-        pend = self._pending
-        if pend is None:
-            raise RuntimeError("backward called without a preceding get_batch_loss on this model")
-        st = self._state
-        B = st["B"]
-        self.__dict__["_main"] = None  # the autograd engine thread has its own notion of the current stream
-        self._assign_grad_views()
+    def _scrub_backward(self, pend):
+        """Scrubber heads: MLP backward, seeds into d_mu.  Reads only what the loss section produced (nothing of the decoder's
+        backward), so train.losses runs it early -- beside the fused tail on its side stream -- on the fast path (defer_tail);
+        otherwise it is the first thing backward_from_seeds does."""
+        B = self._state["B"]
         acc = pend.get("accumulate", False)
-        enc, dec, ch = self.encoder, self.decoder, self.ch
         zp = pad16(self.z_dim)
-        d_mu = pend["d_mu"]  # [B, zp] zero-initialised seed for scrubber grads
-        # ---- scrubber heads: MLP backward, seeds into d_mu
+        d_mu = pend["d_mu"]
         # `linear` projections: gradients of their decoders come from the small torch graphs (train.losses collected the
         # loss-side part; the gradient-reversal heads add theirs below)
         if "linear" in self.disentangle and not acc:
@@ -915,6 +908,24 @@ class ResVAE(nn.Module):
                 tmp = self._buf("an.gmu", (B, zp), zero=True)
                 tmp[:, : self.z_dim] = g_in[:B, : self.z_dim] + g_in[B:, : self.z_dim]
                 ops.axpy(1.0, tmp, d_mu)
+        pend["scrub_done"] = True
+
+    def backward_from_seeds(self):
+        """Reverse schedule.  Needs the seeds prepared by train.losses.get_batch_loss:
+        pending = {dy [rows,Cp], kl_scale, d_mu [B,zp] or None, scrub: [...]}"""
+        pend = self._pending
+        if pend is None:
+            raise RuntimeError("backward called without a preceding get_batch_loss on this model")
+        st = self._state
+        B = st["B"]
+        self.__dict__["_main"] = None  # the autograd engine thread has its own notion of the current stream
+        self._assign_grad_views()
+        acc = pend.get("accumulate", False)
+        enc, dec, ch = self.encoder, self.decoder, self.ch
+        zp = pad16(self.z_dim)
+        d_mu = pend["d_mu"]  # [B, zp] zero-initialised seed for scrubber grads
+        if not pend.get("scrub_done"):
+            self._scrub_backward(pend)
         # ---- decoder
         W = self.window
         rows = B * W

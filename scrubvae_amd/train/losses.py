@@ -24,6 +24,7 @@ from .. import ops
 from ..ops import pad16
 
 _TAIL_FORK = os.environ.get("SVAE_TAIL_FORK", "1") != "0"  # env: schedule experiments (0 = the tail stays on the main stream)
+_EARLY_SCRUB = os.environ.get("SVAE_EARLY_SCRUB", "1") != "0"  # (0 = the heads' backward stays in total.backward())
 
 SUPPORTED = ("rotation", "prior", "jpe", "root", "total_correlation")
 
@@ -368,11 +369,20 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 dlv = model._buf("tc.dlv", (B, z))
                 ops.tc_bwd(zc, zcp, mu_b, zp, lv, B, z, lse_l, lse_a, w, d_mu, zp, dlv, z)
 
+    pend = None
+    if train:
+        pend = dict(dy=None, kl_scale=kl_scale, d_mu=d_mu, scrub=scrub, dsigma=dsigma, dlv=dlv, lin_pgrads=lin_pgrads,
+                    accumulate=getattr(model, "accumulate_grads", False))
+        if fork_tail and model.defer_tail and scrub and _EARLY_SCRUB:
+            # fast path: the heads' backward (it reads only what this section produced) also runs beside the tail, instead of
+            # as the first thing of total.backward()
+            model._assign_grad_views()
+            model._scrub_backward(pend)
     if fork_tail:
         dy = join_tail()
     if train:
-        model._pending = dict(dy=dy, kl_scale=kl_scale, d_mu=d_mu, scrub=scrub, dsigma=dsigma, dlv=dlv, lin_pgrads=lin_pgrads,
-                              accumulate=getattr(model, "accumulate_grads", False))
+        pend["dy"] = dy
+        model._pending = pend
         batch_loss["total"] = model.make_total(total.view(()))
     else:
         batch_loss["total"] = total.view(()).clone()
