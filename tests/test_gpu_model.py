@@ -719,3 +719,45 @@ def test_full_scvae_odd_batch_vs_oracle(B, fused, monkeypatch):
     for n, x in g_o.items():
         dd = float((grads[n] - x).abs().max()) / (float(x.abs().max()) + 1e-3 * gmax)
         assert dd < 5e-2, (n, dd)
+
+
+@pytest.mark.gpu
+def test_overlapped_fast_path_equals_serial_schedule():
+    """The schedule of the benchmark / train_epoch fast path -- side streams on, the fused tail forked beside the scrubbing losses,
+    the heads' backward run early beside it (model.defer_tail, train/losses.py) -- against the plain serial schedule on the same
+    model, batch, noise and shuffle: every loss term and every gradient (the orders of a few additions differ, nothing else), and a
+    second model of the process takes its side streams from the same pool."""
+    from scrubvae_amd.train.losses import get_batch_loss
+    from scrubvae_amd.model import residual
+    feats = ["avg_speed_3d", "heading", "ids"]
+    cfg = O.OracleConfig(n_keypts=18, window=64, z_dim=8, kernel=5, channel=(8, 8, 16, 16, 32), diag=True, arena_size=ARENA,
+                         method={"conditional": feats, "grad_reversal": feats, "adversarial_net": ["heading"]}, features=feats,
+                         discrete_classes={"ids": torch.arange(4)})
+    sd = O.init_state_dict(cfg, seed=41)
+    B = 70
+    data = O.synth_batch(cfg, B, seed=42)
+    g = torch.Generator().manual_seed(43)
+    eps, perm = torch.randn(B, 8, generator=g), torch.randperm(B, generator=g)
+    ls = {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_gr": 1.0, "heading_gr": 2.0, "ids_gr": 0.5, "heading_an": 0.5}
+    res, models = [], []
+    for fast in (False, True):
+        model, dis = build_model(cfg, sd)
+        model.train()
+        model.overlap_wgrad = fast
+        model.defer_tail = fast
+        d = to_dev(data)
+        d["eps"] = eps.cuda()
+        bl = get_batch_loss(model, d, model(d), ls, dis, adv_perm={"heading": perm})
+        if fast:
+            assert model._pending.get("scrub_done")  # the heads' backward already ran, beside the tail
+        bl["total"].backward()
+        torch.cuda.synchronize()
+        res.append(({k: float(v.detach()) for k, v in bl.items()}, {k: v.clone() for k, v in model.grads_state_dict().items()}))
+        models.append(model)
+    (l0, g0), (l1, g1) = res
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-6 * max(1.0, abs(l0[k])), k
+    gmax = max(float(x.abs().max()) for x in g0.values())
+    for n in g0:
+        assert float((g0[n] - g1[n]).abs().max()) <= 1e-5 * (float(g0[n].abs().max()) + 1e-3 * gmax), n
+    assert models[1]._sides and all(a is b for a, b in zip(models[1]._sides, residual._SIDE_STREAMS[0]))
