@@ -1027,10 +1027,19 @@ extern "C" int svae_colsum_batched(const svae_colsum_task* tasks, int n, void* w
                  SVAE_ERR_ARG, "colsum_batched: bad task %d", t);
     T.x[t] = tasks[t].x; T.out[t] = tasks[t].out; T.rows[t] = tasks[t].rows; T.C[t] = tasks[t].C; T.ld[t] = tasks[t].ld;
     const int chunks = (int)((tasks[t].rows + CS_ROWS - 1) / CS_ROWS);
-    T.part_off[t] = off;
-    off += (long long)chunks * tasks[t].C;
+    // the same matrix queued twice (the second conv and the skip conv of a residual block share their dY): the later task reads
+    // the earlier one's partials and owns no stage-1 blocks
+    int same = -1;
+    for (int u = 0; u < t && same < 0; ++u)
+      if (tasks[u].x == tasks[t].x && tasks[u].rows == tasks[t].rows && tasks[u].C == tasks[t].C && tasks[u].ld == tasks[t].ld) same = u;
     T.blk_begin[t] = blk;
-    blk += chunks * ((tasks[t].C + 63) / 64);
+    if (same >= 0) {
+      T.part_off[t] = T.part_off[same];
+    } else {
+      T.part_off[t] = off;
+      off += (long long)chunks * tasks[t].C;
+      blk += chunks * ((tasks[t].C + 63) / 64);
+    }
     T.col_begin[t] = col;
     col += tasks[t].C;
   }

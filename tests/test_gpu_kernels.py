@@ -255,6 +255,32 @@ def test_small_solve_vs_fp64(ops, n, nrhs, batch, with_diag):
     assert torch.equal(one, out[0])  # the unbatched call is the same kernel on one system
 
 
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_colsum_batched_with_shared_matrices(ops, accumulate):
+    """Bias gradients (column sums of every conv's dY, autograd of the reference's `bias=True` convs) in two launches for a list of
+    tasks; a matrix queued twice -- the second conv and the skip conv of a residual block share their dY -- is read once, both
+    outputs get the sums."""
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(1500, 48, generator=g).cuda()
+    Bm = torch.randn(700, 80, generator=g).cuda()[:, :64]  # ld 80, 64 columns
+    Cc = torch.randn(513, 16, generator=g).cuda()
+    outs = [torch.full((48,), 0.5, device="cuda"), torch.full((64,), 0.5, device="cuda"), torch.full((48,), -1.0, device="cuda"),
+            torch.full((16,), 0.5, device="cuda"), torch.full((64,), 2.0, device="cuda")]
+    init = [o.clone() for o in outs]
+    batch = ops.ColsumBatch()
+    for x, o in zip((A, Bm, A, Cc, Bm), outs):
+        batch.add(x, x.shape[0], x.shape[1], x.stride(0), o)
+    ws = {}
+    def get_ws(n):
+        ws["t"] = torch.empty(n // 4 + 16, device="cuda")
+        return ws["t"]
+    batch.flush(get_ws, accumulate=accumulate)
+    for x, o, o0 in zip((A, Bm, A, Cc, Bm), outs, init):
+        ref = x.double().sum(0) + (o0.double() if accumulate else 0)
+        assert float((o.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max() + 1)
+    assert torch.equal(outs[0] - (init[0] if accumulate else 0), outs[2] - (init[2] if accumulate else 0)) or accumulate
+
+
 def test_small_inverse_autograd_vs_fp64(ops):
     """LinearProjection's (W W^T)^-1 (reference disentangle.py:717-734: torch.linalg.solve(nrm, x.T)) through ops.small_inverse_autograd:
     the value and the gradient with respect to W of the projected latent against fp64 autograd."""
