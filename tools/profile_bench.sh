@@ -12,8 +12,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
 cd /tmp && export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --no-secondary --no-roofline"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" "$@" $COMMON --steps 20 --warmup 5 > "$OUT/trace.json" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -o t -- python3 "$ROOT/bench.py" "$@" $COMMON --serial-streams --steps 20 --warmup 5 > "$OUT/trace_serial.json" 2> "$OUT/trace_serial.err" || { tail -5 "$OUT/trace_serial.err"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" "$@" $COMMON --steps 100 --warmup 5 > "$OUT/trace.json" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -o t -- python3 "$ROOT/bench.py" "$@" $COMMON --serial-streams --steps 100 --warmup 5 > "$OUT/trace_serial.json" 2> "$OUT/trace_serial.err" || { tail -5 "$OUT/trace_serial.err"; exit 1; }
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_util" -o t -- python3 "$ROOT/bench.py" "$@" $COMMON --serial-streams --steps 3 --warmup 2 > "$OUT/pmc_util.json" 2> "$OUT/pmc_util.err" || { tail -5 "$OUT/pmc_util.err"; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o t -- python3 "$ROOT/bench.py" "$@" $COMMON --serial-streams --steps 3 --warmup 2 > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || { tail -5 "$OUT/pmc_fetch.err"; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o t -- python3 "$ROOT/bench.py" "$@" $COMMON --serial-streams --steps 3 --warmup 2 > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err" || { tail -5 "$OUT/pmc_write.err"; exit 1; }
