@@ -77,6 +77,7 @@ def parse():
                          "contractions; bf16x6b3 = 3 products for the whole backward pass, 6 for the forward; f16x3b3 = forward with two "
                          "FP16 pieces / 3 products (22-bit operands, ~2^-22 per product), backward as bf16x6b3; bf16x3 / bf16 = "
                          "2 / 1 pieces everywhere (reduced accuracy, study only)")
+    ap.add_argument("--overlap-streams", action="store_true", help="side streams on at any batch (default: from 32768 batch x window rows)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="timed region without the concurrent side streams (what the roofline region always uses)")
     ap.add_argument("--h2d", action="store_true",
@@ -281,6 +282,8 @@ def run_workload(args, full, B, rank, world, roofline=True):
         step()
     if args.serial_streams:
         model.overlap_wgrad = False
+    elif args.overlap_streams:
+        model.overlap_wgrad = True
     # ---- headline timed region: exactly K steps, barrier + synchronize on both sides, no per-launch instrumentation
     barrier()
     t0 = time.perf_counter()
