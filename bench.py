@@ -322,7 +322,7 @@ def run_workload(args, full, B, rank, world, roofline=True):
         dt = float(tt)
     res = {"value": round(B * world * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 3),
            "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3), "final_total_loss": float(bl["total"].detach()),
-           "side_streams": bool(model._ov) and not args.serial_streams,
+           "side_streams": int(model._ov) if not args.serial_streams else 0,
            "workload": workload_name(args, full, B), "batch_per_gpu": B}
     if timer is not None:
         summ = timer.summary()
@@ -402,7 +402,9 @@ def main():
                        "joints": args.joints, "launch": "hipGraph replay" if args.graph else "eager launches",
                        "inputs": ("copied from pinned host memory for every step, one batch ahead on a copy stream (PCIe-inclusive)"
                                   if args.h2d else "resident in HBM"),
-                       "streams": "3 HIP streams (weight gradients / skip branches overlap the main chain)" if head["side_streams"] else "one stream (serialised: chosen below 32768 batch x window rows, or --serial-streams)",
+                       "streams": {2: "3 HIP streams (weight gradients / skip branches / the tail overlap the main chain)",
+                                   1: "2 HIP streams (weight gradients beside the main chain: chosen from 8192 batch x window rows)",
+                                   0: "one stream (serialised: chosen below 8192 batch x window rows, or --serial-streams)"}[int(head["side_streams"])],
                        "precision": precision_text(args.precision),
                        "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("+syncbn" if args.sync_bn else "+localbn")),

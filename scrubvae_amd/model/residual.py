@@ -18,6 +18,8 @@ runs the reverse schedule.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -190,7 +192,7 @@ class ResVAE(nn.Module):
         # cost (measured on configs[1]: B=32 8.3k -> 14k, B=256 51k -> 77k windows/s WITHOUT the side streams; B=1024 194k -> 212k with)
         self.overlap_wgrad = None
         self.overlap_min_rows = 32768
-        self._ov = True
+        self._ov = 2
         self._sides, self._side_dirty, self._events, self._event_i = [], set(), [], 0
         self._ws = {}
         self._convs = {}
@@ -375,10 +377,21 @@ class ResVAE(nn.Module):
         self._event_i = (self._event_i + 1) % 64
         return self._events[self._event_i]
 
+    def _overlap_level(self, B):
+        """Stream schedule of a pass over B windows: 2 = weight gradients, skip branches and the fused tail on side streams
+        (from `overlap_min_rows` batch x window rows), 1 = only the weight gradients leave the main stream (from a quarter of
+        that: B = 128-511 at window 64 measured 3-5 % over the serial schedule, the full one loses there), 0 = one stream
+        (below: every cross-stream hand-over costs more than it overlaps).  `overlap_wgrad` = True / False / 0..2 overrides."""
+        ow = self.overlap_wgrad
+        if ow is not None:
+            return 2 if ow is True else int(ow)
+        rows = B * self.window
+        return 2 if rows >= self.overlap_min_rows else (1 if rows * 4 >= self.overlap_min_rows else 0)
+
     def _fork(self, fn, k=1):
         """Run fn() on side stream k, ordered after everything queued on the main stream so far.
         Stream 0 carries the weight gradients, stream 1 the skip branches."""
-        if not self._ov:
+        if not self._ov or (k != 0 and self._ov == 1):
             return fn()
         main = self._main_stream()
         side = self._side_stream(k)
@@ -729,7 +742,7 @@ class ResVAE(nn.Module):
     def encode(self, data):
         """ResVAE.encode (residual.py:438-459): returns {"mu": [B,z], "L": [B,z,z]}."""
         self._new_pass()
-        self._ov = (data["x6d"].shape[0] * self.window >= self.overlap_min_rows) if self.overlap_wgrad is None else bool(self.overlap_wgrad)
+        self._ov = self._overlap_level(data["x6d"].shape[0])
         B, flat, h = self._encode_trunk(data)
         mu, sigma, zc, klp = self._heads(B, h, None)
         self._state = dict(B=B, flat=flat, h=h, eps=None)
@@ -739,7 +752,7 @@ class ResVAE(nn.Module):
         """ResVAE.decode (residual.py:461-491)."""
         self._new_pass()
         B = z.shape[0]
-        self._ov = (B * self.window >= self.overlap_min_rows) if self.overlap_wgrad is None else bool(self.overlap_wgrad)
+        self._ov = self._overlap_level(B)
         zcp = pad16(self.z_dim + self.conditional_dim)
         zc = self._buf("dec.zc", (B, zcp), zero=True)
         zc[:, : self.z_dim] = z.to(self.device)
@@ -763,7 +776,7 @@ class ResVAE(nn.Module):
         """VAE.forward (residual.py:318-362).  Returns data_o with mu, L, z, x6d, root, var,
         disentangle[method][feature]."""
         self._new_pass()
-        self._ov = (data["x6d"].shape[0] * self.window >= self.overlap_min_rows) if self.overlap_wgrad is None else bool(self.overlap_wgrad)
+        self._ov = self._overlap_level(data["x6d"].shape[0])
         B, flat, h = self._encode_trunk(data)
         eps = None
         if self.training:

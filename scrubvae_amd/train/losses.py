@@ -100,7 +100,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     def _tail():
         tail_out["r"] = model._run_tail(B, dev_data, jpe_s, root_s, ext_dx6d, train)
 
-    fork_tail = model._ov and _TAIL_FORK
+    fork_tail = model._ov == 2 and _TAIL_FORK
     if fork_tail:
         model._fork(_tail, k=1)
     else:
