@@ -761,3 +761,43 @@ def test_overlapped_fast_path_equals_serial_schedule():
     for n in g0:
         assert float((g0[n] - g1[n]).abs().max()) <= 1e-5 * (float(g0[n].abs().max()) + 1e-3 * gmax), n
     assert models[1]._sides and all(a is b for a, b in zip(models[1]._sides, residual._SIDE_STREAMS[0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast", [False, True])
+def test_accumulate_grads_adds_a_second_backward(fast):
+    """model.accumulate_grads = True makes total.backward() ADD to the gradients (gradient accumulation over micro-batches):
+    the same batch twice gives twice the gradients of one pass -- on the serial schedule and on the overlapped fast path (tail and
+    heads' backward beside each other, bias-gradient sums sharing a dY)."""
+    from scrubvae_amd.train.losses import get_batch_loss
+    feats = ["avg_speed_3d", "heading", "ids"]
+    cfg = O.OracleConfig(n_keypts=18, window=64, z_dim=8, kernel=5, channel=(8, 8, 16, 16, 32), diag=True, arena_size=ARENA,
+                         method={"conditional": feats, "grad_reversal": feats, "adversarial_net": ["heading"]}, features=feats,
+                         discrete_classes={"ids": torch.arange(4)})
+    sd = O.init_state_dict(cfg, seed=51)
+    B = 37
+    data = O.synth_batch(cfg, B, seed=52)
+    g = torch.Generator().manual_seed(53)
+    eps, perm = torch.randn(B, 8, generator=g), torch.randperm(B, generator=g)
+    ls = {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_gr": 1.0, "heading_gr": 2.0, "ids_gr": 0.5, "heading_an": 0.5}
+    model, dis = build_model(cfg, sd)
+    model.train()
+    model.overlap_wgrad = fast
+    model.defer_tail = fast
+    d = to_dev(data)
+    d["eps"] = eps.cuda()
+
+    def one_pass():
+        bl = get_batch_loss(model, d, model(d), ls, dis, adv_perm={"heading": perm})
+        bl["total"].backward()
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in model.grads_state_dict().items()}
+
+    g1 = one_pass()
+    model.accumulate_grads = True
+    g2 = one_pass()
+    gmax = max(float(x.abs().max()) for x in g1.values())
+    for n in g1:
+        if n.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            continue
+        assert float((g2[n] - 2 * g1[n]).abs().max()) <= 2e-5 * (float(g1[n].abs().max()) + 1e-3 * gmax), n
