@@ -210,6 +210,17 @@ int svae_affine_prelu_bwd_apply(const float* dy, const float* x, const float* sc
                                 float* dgamma, float* dbeta, float* dalpha,
                                 const float* dalpha_part, int n_parts, int accumulate_param_grads,
                                 void* stream);   /* n_parts = entries of dalpha_part */
+/* the same pass, also leaving the column sums of dx -- the bias gradient of the conv(s) in front of the stage (autograd of the
+ * reference's `bias=True` convs) -- as per-workgroup partials colsum_part[svae_affine_prelu_colsum_rows(rows, C)][C] for
+ * svae_colsum_from_partials (needs C / 4 a power of two <= 256; colsum_part may be NULL) */
+int svae_affine_prelu_colsum_rows(long long rows, int C);
+int svae_affine_prelu_bwd_apply_colsum(const float* dy, const float* x, const float* scale, const float* shift,
+                                       const float* mean, const float* rstd, const float* gamma,
+                                       const float* alpha, const float* sums, double count,
+                                       float* dx, long long rows, int C, int ld,
+                                       float* dgamma, float* dbeta, float* dalpha,
+                                       const float* dalpha_part, int n_parts, int accumulate_param_grads,
+                                       float* colsum_part, void* stream);
 
 /* nn.Upsample(scale_factor=2, mode="linear", align_corners=False) (residual.py:160) */
 int svae_upsample2_fwd(const float* x, float* y, int batch, int l_in, int C, int ld, void* stream);
@@ -300,6 +311,13 @@ typedef struct {
   long long rows;
   int C, ld;
 } svae_colsum_task;
+/* out[c] (+)= sum over rows of part[rows][C] for up to SVAE_MAX_COLSUM_TASKS partial arrays in one launch (fp64, fixed order) */
+typedef struct {
+  const float* part;
+  float* out;
+  int rows, C;
+} svae_colsum_part_task;
+int svae_colsum_from_partials(const svae_colsum_part_task* tasks, int n, int accumulate, void* stream);
 size_t svae_colsum_batched_workspace(const svae_colsum_task* tasks, int n);
 int svae_colsum_batched(const svae_colsum_task* tasks, int n, void* ws, size_t ws_bytes, int accumulate,
                         void* stream);

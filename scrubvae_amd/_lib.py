@@ -27,6 +27,10 @@ class ColsumTask(C.Structure):
 MAX_COLSUM_TASKS = 48
 
 
+class ColsumPartTask(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int), ("C", C.c_int)]
+
+
 class SplitTask(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wsplit", C.c_void_p), ("kernel", C.c_int), ("c_in", C.c_int), ("c_out", C.c_int)]
 
@@ -117,6 +121,9 @@ SIGNATURES = {
     "svae_affine_prelu_fwd": (I, [P, P, P, P, P, LL, I, I, P]),
     "svae_affine_prelu_bwd_partial": (I, [P, P, P, P, P, P, P, LL, I, I, P, P, P]),
     "svae_affine_prelu_bwd_apply": (I, [P, P, P, P, P, P, P, P, P, D, P, LL, I, I, P, P, P, P, I, I, P]),
+    "svae_affine_prelu_bwd_apply_colsum": (I, [P, P, P, P, P, P, P, P, P, D, P, LL, I, I, P, P, P, P, I, I, P, P]),
+    "svae_affine_prelu_colsum_rows": (I, [LL, I]),
+    "svae_colsum_from_partials": (I, [C.POINTER(ColsumPartTask), I, I, P]),
     "svae_upsample2_fwd": (I, [P, P, I, I, I, I, P]),
     "svae_upsample2_bwd": (I, [P, P, I, I, I, I, I, P]),
     "svae_heads_diag_fwd": (I, [P, I, P, P, P, P, I, P, I, I, I, I, P]),

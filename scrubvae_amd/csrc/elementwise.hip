@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_apply_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
     const float* __restrict__ alpha, const float* __restrict__ sums, float inv_count, float* __restrict__ dx, long long rows,
-    int C, int ld) {
+    int C, int ld, float* __restrict__ colsum_part) {
   const bool th = alpha == nullptr;
   const float a = th ? 0.f : alpha[0];
   const int C4 = C / 4;
@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_apply_kernel(
       s1[0] = q4.x; s1[1] = q4.y; s1[2] = q4.z; s1[3] = q4.w;
     }
     const long long rstep = ((long long)gridDim.x * 256) >> sh;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
     for (long long r = ((long long)blockIdx.x * 256 + threadIdx.x) >> sh; r < rows; r += rstep) {
       const float4 xv4 = ld4(x + r * ld + c), dv4 = ld4(dy + r * ld + c);
       const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
@@ -345,6 +346,24 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_apply_kernel(
         }
       }
       st4(dx + r * ld + c, make_float4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cs[k] += o[k];
+    }
+    // column sums of dx = the bias gradient of the conv(s) in front of this stage (autograd of `bias=True`): the values are in
+    // registers here, so the separate pass over dx is saved.  colsum_part[gridDim.x][C]: one row per workgroup, summed in row
+    // order by svae_colsum_from_partials (deterministic).
+    if (colsum_part != nullptr) {  // uniform
+      __shared__ float red[256][5];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = cs[k];
+      __syncthreads();
+      if ((int)threadIdx.x < C4) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = threadIdx.x; j < 256; j += C4)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) t[k] += red[j][k];
+        st4(colsum_part + (long long)blockIdx.x * C + c, make_float4(t[0], t[1], t[2], t[3]));
+      }
     }
     return;
   }
@@ -856,15 +875,33 @@ extern "C" int svae_affine_prelu_bwd_partial(const float* dy, const float* x, co
   return check_launch("affine_prelu_bwd_partial");
 }
 
+/* rows of colsum_part the apply pass writes (= its grid: at most 1024 workgroups, so that the partials stay small) */
+extern "C" int svae_affine_prelu_colsum_rows(long long rows, int C) { return grid_for(rows * (C / 4), 256, 1024); }
+
 extern "C" int svae_affine_prelu_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift,
                                            const float* mean, const float* rstd, const float* gamma, const float* alpha,
                                            const float* sums, double count, float* dx, long long rows, int C, int ld,
                                            float* dgamma, float* dbeta, float* dalpha, const float* dalpha_part, int n_parts,
                                            int accumulate_param_grads, void* stream) {
+  return svae_affine_prelu_bwd_apply_colsum(dy, x, scale, shift, mean, rstd, gamma, alpha, sums, count, dx, rows, C, ld, dgamma, dbeta,
+                                            dalpha, dalpha_part, n_parts, accumulate_param_grads, nullptr, stream);
+}
+
+extern "C" int svae_affine_prelu_bwd_apply_colsum(const float* dy, const float* x, const float* scale, const float* shift,
+                                                  const float* mean, const float* rstd, const float* gamma, const float* alpha,
+                                                  const float* sums, double count, float* dx, long long rows, int C, int ld,
+                                                  float* dgamma, float* dbeta, float* dalpha, const float* dalpha_part, int n_parts,
+                                                  int accumulate_param_grads, float* colsum_part, void* stream) {
   SVAE_REQUIRE(dy && x && dx && rows > 0, SVAE_ERR_ARG, "affine_prelu_bwd_apply: null pointer");
   SVAE_REQUIRE(!sums || (mean && rstd && gamma && count > 0), SVAE_ERR_ARG, "affine_prelu_bwd_apply: BN tensors missing");
-  hipLaunchKernelGGL(affine_prelu_bwd_apply_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, ST(stream), dy, x, scale, shift,
-                     mean, rstd, gamma, alpha, sums, sums ? (float)(1.0 / count) : 0.f, dx, rows, C, ld);
+  if (colsum_part) {
+    const int C4 = C / 4;
+    SVAE_REQUIRE(C % 4 == 0 && (C4 & (C4 - 1)) == 0 && C4 <= 256 && aligned16(colsum_part), SVAE_ERR_SHAPE,
+                 "affine_prelu_bwd_apply: column sums need C / 4 a power of two <= 256");
+  }
+  const int grid = colsum_part ? svae_affine_prelu_colsum_rows(rows, C) : grid_for(rows * (C / 4));
+  hipLaunchKernelGGL(affine_prelu_bwd_apply_kernel, dim3(grid), dim3(256), 0, ST(stream), dy, x, scale, shift,
+                     mean, rstd, gamma, alpha, sums, sums ? (float)(1.0 / count) : 0.f, dx, rows, C, ld, colsum_part);
   if (int e = check_launch("affine_prelu_bwd_apply")) return e;
   if (dgamma || dbeta || dalpha) {
     hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), sums, C, dgamma, dbeta, dalpha,
@@ -1060,4 +1097,56 @@ extern "C" int svae_colsum_batched(const svae_colsum_task* tasks, int n, void* w
   if (int e = check_launch("colsum_batched_partial")) return e;
   hipLaunchKernelGGL(colsum_batched_final_kernel, dim3((col + 7) / 8), dim3(256), 0, ST(stream), T, (const float*)ws, accumulate);
   return check_launch("colsum_batched_final");
+}
+
+// column sums from partials other kernels left behind (affine_prelu_bwd_apply_kernel): task t: out[c] (+)= sum over rows of part[rows][C],
+// 32 row-lanes per column in fp64, combined in lane order (deterministic)
+struct ColsumPartTasks {
+  const float* part[SVAE_MAX_COLSUM_TASKS];
+  float* out[SVAE_MAX_COLSUM_TASKS];
+  int rows[SVAE_MAX_COLSUM_TASKS], C[SVAE_MAX_COLSUM_TASKS];
+  int col_begin[SVAE_MAX_COLSUM_TASKS + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void colsum_from_partials_kernel(const ColsumPartTasks T, int accumulate) {
+  __shared__ double red[32][8];
+  const int cl = threadIdx.x & 7, sub = threadIdx.x >> 3;
+  const int gc = blockIdx.x * 8 + cl;
+  const bool ok = gc < T.col_begin[T.n];
+  int t = 0, c = 0, C = 1, rows = 0;
+  if (ok) {
+    while (t + 1 < T.n && gc >= T.col_begin[t + 1]) ++t;
+    c = gc - T.col_begin[t];
+    C = T.C[t];
+    rows = T.rows[t];
+  }
+  double s = 0.0;
+  for (int k = sub; k < rows; k += 32) s += (double)T.part[t][(long long)k * C + c];
+  red[sub][cl] = s;
+  __syncthreads();
+  if (sub == 0 && ok) {
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) tot += red[i][cl];
+    float* o = T.out[t];
+    o[c] = (accumulate ? o[c] : 0.f) + (float)tot;
+  }
+}
+
+extern "C" int svae_colsum_from_partials(const svae_colsum_part_task* tasks, int n, int accumulate, void* stream) {
+  SVAE_REQUIRE(tasks && n > 0 && n <= SVAE_MAX_COLSUM_TASKS, SVAE_ERR_ARG, "colsum_from_partials: bad args (n=%d)", n);
+  ColsumPartTasks T;
+  memset(&T, 0, sizeof(T));
+  T.n = n;
+  int col = 0;
+  for (int t = 0; t < n; ++t) {
+    SVAE_REQUIRE(tasks[t].part && tasks[t].out && tasks[t].rows > 0 && tasks[t].C > 0, SVAE_ERR_ARG, "colsum_from_partials: bad task %d", t);
+    T.part[t] = tasks[t].part; T.out[t] = tasks[t].out; T.rows[t] = tasks[t].rows; T.C[t] = tasks[t].C;
+    T.col_begin[t] = col;
+    col += tasks[t].C;
+  }
+  T.col_begin[n] = col;
+  hipLaunchKernelGGL(colsum_from_partials_kernel, dim3((col + 7) / 8), dim3(256), 0, ST(stream), T, accumulate);
+  return check_launch("colsum_from_partials");
 }

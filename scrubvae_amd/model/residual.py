@@ -51,6 +51,7 @@ def find_out_dim(latent_dim, kernel, num_layers, dilation=None):
     return int(l_out)
 
 
+_APPLY_COLSUM = os.environ.get("SVAE_APPLY_COLSUM", "1") != "0"  # env: experiments (0 = bias gradients by a separate pass over dY)
 _SIDE_STREAMS = {}  # device index -> side streams shared by every model of the process (see ResVAE._side_stream)
 
 
@@ -200,6 +201,7 @@ class ResVAE(nn.Module):
         self._runners = {}
         self._pending = None
         self._db_batch = ops.ColsumBatch()
+        self._dx_colsum = {}  # data_ptr of a dX produced by a backward apply pass -> (partials, their rows, rows, Cp)
         self._tree = make_tree(self.n_keypts, kinematic_tree) if kinematic_tree is not None else None
         self._arena_host = None if arena_size is None else [float(v) for v in torch.as_tensor(arena_size).flatten()]
         self._materialise(torch.device(device))
@@ -356,7 +358,22 @@ class ResVAE(nn.Module):
         stream is forked from the main stream after `dy` is produced and joined before anything
         consumes the gradients (_join_side)."""
         self._fork(lambda: cv.wgrad(x, dy, p.weight.grad, None, self._wgrad_ws(cv), accumulate=acc), k=0)
-        self._db_batch.add(dy, cv.batch * cv.l_out, cv.c_out_p, cv.desc.ld_out, p.bias.grad)
+        ent = self._dx_colsum.get(dy.data_ptr())
+        if ent is not None and ent[2:] == (cv.batch * cv.l_out, cv.c_out_p) and cv.desc.ld_out == cv.c_out_p:
+            # dy came out of a BatchNorm / activation backward pass that left its column sums behind
+            self._db_batch.add_partials(ent[0], ent[1], cv.c_out_p, p.bias.grad)
+        else:
+            self._db_batch.add(dy, cv.batch * cv.l_out, cv.c_out_p, cv.desc.ld_out, p.bias.grad)
+
+    def _dx_colsum_part(self, tag, dx, rows, Cp):
+        """Buffer for the column-sum partials of `dx` written by the backward apply pass of stage `tag` (None where the kernel cannot
+        produce them); remembered by the address of dx so that _wgrad finds them when dx is a conv's dY."""
+        n = ops.affine_prelu_colsum_rows(rows, Cp) if _APPLY_COLSUM else 0
+        if n == 0:
+            return None
+        part = self._buf(f"{tag}.dbpart", (n, Cp))
+        self._dx_colsum[dx.data_ptr()] = (part, n, rows, Cp)
+        return part
 
     def _side_stream(self, k=0):
         """Side stream k of this model's device, from a PROCESS-WIDE pool: the runtime multiplexes streams onto a few hardware
@@ -575,7 +592,8 @@ class ResVAE(nn.Module):
             gl.copy_(sums)
             self._allreduce(gl)
             ops.affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, bn.weight, act.weight, gl, rows * self.world_size,
-                                       dx, rows, Cp, Cp, None, None, slope_grad(act), dap, dap.numel(), acc)
+                                       dx, rows, Cp, Cp, None, None, slope_grad(act), dap, dap.numel(), acc,
+                                       colsum_part=self._dx_colsum_part(tag, dx, rows, Cp))
             if acc:
                 ops.axpy(1.0, sums[0], bn.bias.grad)
                 ops.axpy(1.0, sums[1], bn.weight.grad)
@@ -585,7 +603,7 @@ class ResVAE(nn.Module):
         else:
             ops.bn_bwd_reduce(part, nch, Cp, sums, bn.weight.grad, bn.bias.grad, slope_grad(act), dap, dap.numel(), acc)
             ops.affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, bn.weight, act.weight, sums, count, dx, rows, Cp, Cp,
-                                       None, None, None, dap, dap.numel(), acc)
+                                       None, None, None, dap, dap.numel(), acc, colsum_part=self._dx_colsum_part(tag, dx, rows, Cp))
         return dx
 
     # ------------------------------------------------------------------ forward pieces
@@ -933,6 +951,7 @@ class ResVAE(nn.Module):
         B = st["B"]
         self.__dict__["_main"] = None  # the autograd engine thread has its own notion of the current stream
         self._assign_grad_views()
+        self._dx_colsum = {}
         acc = pend.get("accumulate", False)
         enc, dec, ch = self.encoder, self.decoder, self.ch
         zp = pad16(self.z_dim)
@@ -1085,7 +1104,8 @@ class ResVAE(nn.Module):
             ops.affine_prelu_bwd_partial(g, c0, None, None, None, None, enc.activation.weight, rows, C0, C0, part, dap)
         g_c0 = self._buf("g.enc.c_in", (rows, C0))
         ops.affine_prelu_bwd_apply(g, c0, None, None, None, None, None, enc.activation.weight, None, 1.0, g_c0, rows, C0, C0,
-                                   None, None, slope_grad(enc.activation), dap, dap.numel(), acc)
+                                   None, None, slope_grad(enc.activation), dap, dap.numel(), acc,
+                                   colsum_part=self._dx_colsum_part("enc.in", g_c0, rows, C0))
         x_in = self._buf("x_in", (rows, pad16(self.in_channels)))
         cvi = self._conv("enc.conv_in", enc.conv_in, B, W)
         self._wgrad(cvi, x_in, g_c0, enc.conv_in, acc)

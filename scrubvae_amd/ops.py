@@ -589,11 +589,23 @@ class ColsumBatch:
 
     def __init__(self):
         self.tasks = []
+        self.part_tasks = []
 
     def add(self, x, rows, Cp, ld, out):
         self.tasks.append((x, rows, Cp, ld, out))
 
+    def add_partials(self, part, rows, Cp, out):
+        """out = column sums of part [rows, Cp] (partials another kernel left behind: ops.affine_prelu_bwd_apply)"""
+        self.part_tasks.append((part, rows, Cp, out))
+
     def flush(self, get_ws, accumulate=False):
+        for i in range(0, len(self.part_tasks), _lib.MAX_COLSUM_TASKS):
+            chunk = self.part_tasks[i: i + _lib.MAX_COLSUM_TASKS]
+            arr = (_lib.ColsumPartTask * len(chunk))()
+            for t, (part, rows, Cp, out) in zip(arr, chunk):
+                t.part, t.out, t.rows, t.C = part.data_ptr(), out.data_ptr(), rows, Cp
+            check(_lib.lib().svae_colsum_from_partials(arr, len(chunk), int(accumulate), _stream()), "colsum_from_partials")
+        self.part_tasks = []
         for i in range(0, len(self.tasks), _lib.MAX_COLSUM_TASKS):
             chunk = self.tasks[i: i + _lib.MAX_COLSUM_TASKS]
             arr = (_lib.ColsumTask * len(chunk))()
@@ -620,10 +632,21 @@ def affine_prelu_bwd_partial(dy, x, scale, shift, mean, rstd, alpha, rows, Cp, l
 
 
 def affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, gamma, alpha, sums, count, dx, rows, Cp, ld,
-                           dgamma, dbeta, dalpha, dalpha_part, n_parts, accumulate):
-    check(_lib.lib().svae_affine_prelu_bwd_apply(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(gamma), _p(alpha),
-                                                 _p(sums), float(count), _p(dx), rows, Cp, ld, _p(dgamma), _p(dbeta), _p(dalpha),
-                                                 _p(dalpha_part), n_parts, int(accumulate), _stream()), "affine_prelu_bwd_apply")
+                           dgamma, dbeta, dalpha, dalpha_part, n_parts, accumulate, colsum_part=None):
+    """colsum_part [affine_prelu_colsum_rows(rows, Cp), Cp]: the pass also leaves the column sums of dx (the bias gradient of the
+    conv(s) in front of the stage) as per-workgroup partials for ColsumBatch.add_partials."""
+    check(_lib.lib().svae_affine_prelu_bwd_apply_colsum(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(gamma), _p(alpha),
+                                                        _p(sums), float(count), _p(dx), rows, Cp, ld, _p(dgamma), _p(dbeta), _p(dalpha),
+                                                        _p(dalpha_part), n_parts, int(accumulate), _p(colsum_part), _stream()),
+          "affine_prelu_bwd_apply")
+
+
+def affine_prelu_colsum_rows(rows, Cp):
+    """Rows of the colsum_part array of affine_prelu_bwd_apply; 0 where the pass cannot produce the sums (channel count)."""
+    c4 = Cp // 4
+    if Cp % 4 or c4 & (c4 - 1) or c4 > 256:
+        return 0
+    return int(_lib.lib().svae_affine_prelu_colsum_rows(rows, Cp))
 
 
 def upsample2_fwd(x, y, batch, l_in, Cp, ld):

@@ -159,6 +159,33 @@ def test_bn_prelu_fwd_bwd(ops, rows, Cc):
     assert relerr(da.cpu(), alpha.grad) < 2e-5
 
 
+@pytest.mark.parametrize("rows,Cc,accumulate", [(5000, 64, False), (70000, 256, True), (37, 16, False), (300000, 1024, False)])
+def test_backward_apply_leaves_the_column_sums_of_dx(ops, rows, Cc, accumulate):
+    """The bias gradient of a conv whose output feeds an activation stage = column sums of that stage's dx (autograd of the
+    reference's `bias=True` convs): ops.affine_prelu_bwd_apply leaves per-workgroup partials, ColsumBatch.add_partials reduces
+    them -- against the sums of the dx the same launch wrote (bare PReLU stage: the sums are far from zero)."""
+    g = torch.Generator().manual_seed(rows + Cc)
+    x = torch.randn(rows, Cc, generator=g).cuda()
+    dy = (torch.randn(rows, Cc, generator=g) + 0.3).cuda()
+    alpha = torch.tensor([0.25], device="cuda")
+    n = ops.affine_prelu_colsum_rows(rows, Cc)
+    assert 0 < n <= 1024
+    part = torch.full((n, Cc), float("nan"), device="cuda")
+    dx = torch.empty_like(x)
+    dap = torch.zeros(4, device="cuda")
+    ops.affine_prelu_bwd_apply(dy, x, None, None, None, None, None, alpha, None, 1.0, dx, rows, Cc, Cc, None, None, None, dap, 0,
+                               False, colsum_part=part)
+    ref_dx = torch.where(x > 0, dy, 0.25 * dy)
+    assert torch.equal(dx, ref_dx)
+    out = torch.full((Cc,), 3.0, device="cuda")
+    batch = ops.ColsumBatch()
+    batch.add_partials(part, n, Cc, out)
+    batch.flush(lambda nbytes: torch.empty(nbytes // 4 + 16, device="cuda"), accumulate=accumulate)
+    ref = dx.double().sum(0) + (3.0 if accumulate else 0.0)
+    assert float((out.double() - ref).abs().max()) < 2e-6 * float(dx.double().abs().sum(0).max())
+    assert ops.affine_prelu_colsum_rows(100, 48) == 0 and ops.affine_prelu_colsum_rows(100, 144) == 0  # C / 4 not a power of two
+
+
 @pytest.mark.parametrize("rows,Cc", [(700, 48), (37, 16)])
 def test_bn_tanh_fwd_bwd(ops, rows, Cc):
     """model.activation == "tanh": the same kernels with a NULL slope pointer = train-mode BatchNorm + tanh, vs torch fp64."""
