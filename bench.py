@@ -2,7 +2,9 @@
 """Headline benchmark: pose-windows/sec through one full SC-VAE optimizer step on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, one rank per
+     process, or as typed above: outside a torchrun environment the process becomes a launcher that starts exactly that command
+     as a child without ever touching the GPU itself -- launch_ranks())
 
 Headline workload = BASELINE.json configs[2] (the N=1 point of the configs[3] data-parallel series): the FULL SC-VAE --
 conditional decoder + two gradient-reversal ensembles + the adversarial net -- on synthetic 64-frame, 23-joint mouse
@@ -118,14 +120,19 @@ def build_model(args, full, method, feats, tree):
 
 
 def workload_name(args, full, B):
-    base = ("configs[2] full SC-VAE (conditional + grad_reversal x2 + adversarial_net), AdamW" if full else
-            "configs[4] wide six-block rcnn, recon+KL (jpe+root+prior), AdamW" if args.channel_list == WIDE6 else
+    wide = args.channel_list == WIDE6
+    base = ("configs[4] wide six-block rcnn (channels to 4096, long window), full SC-VAE heads (conditional + grad_reversal x2 + "
+            "adversarial_net), AdamW" if (wide and full) else
+            "configs[2] full SC-VAE (conditional + grad_reversal x2 + adversarial_net), AdamW" if full else
+            "configs[4] wide six-block rcnn, recon+KL (jpe+root+prior), AdamW" if wide else
             "configs[1] mouse-skeleton rcnn, recon+KL (jpe+root+prior), AdamW")
     return base + f", batch {B}/GPU, window {args.window}, {args.joints} joints, z=32, channels [{','.join(map(str, args.channel_list))}]"
 
 
 def profile_tag(args, full, B):
     """Name of the committed PMC summaries of this workload (profiles/r*_pmc_traffic_<tag>.json), None for ad-hoc shapes."""
+    if args.channel_list == WIDE6 and args.window == 256 and args.joints == 23 and full and B == 1024:
+        return "config4_w256_wide6_b1024"
     if args.channel_list != CHANNELS or args.window != 64 or args.joints != 23:
         return None
     if full and B == 4096:
@@ -172,7 +179,7 @@ def cpu_baseline(args, full, B, max_seconds=24.0):
     bl0, _, _, _ = O.train_step(sd, cfg, data, loss, eps, adv_perm=perm, opt_state=state)  # warm-up; also the ELBO reference
     t_first = time.perf_counter() - t0
     elbo = elbo_check(args, full, cfg, sd, data, eps, perm, loss, method, feats, bl0)
-    steps = int(max(2, min(50, max_seconds / max(t_first, 1e-3))))
+    steps = int(max(3, min(50, max_seconds / max(t_first, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(steps):
         _, _, sd, _ = O.train_step(sd, cfg, data, loss, eps, adv_perm=perm, opt_state=state)
@@ -280,6 +287,9 @@ def run_workload(args, full, B, rank, world, roofline=True):
     hp.__enter__()
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        model.time_comm = True  # HIP events around the exposed tail of the gradient exchange (ResVAE.backward_from_seeds)
+        model.pop_comm_times()
     if args.serial_streams:
         model.overlap_wgrad = False
     elif args.overlap_streams:
@@ -292,6 +302,8 @@ def run_workload(args, full, B, rank, world, roofline=True):
     t_host = time.perf_counter() - t0  # all launches of the K steps are queued (the GPU is still working)
     barrier()
     dt = time.perf_counter() - t0
+    ov_timed = 0 if args.serial_streams else int(model._ov)  # the stream schedule the K timed steps actually ran (the regions below change it)
+    comm_ms = model.pop_comm_times() if world > 1 else []
     # ---- roofline region: the same K steps again with the side streams serialised and HIP events around every launch of
     # the dominant GEMM template.  In the headline region three HIP streams run kernels concurrently on shared CUs, so a
     # launch's start-to-end time is not the kernel's own time there; serialised, it is.
@@ -300,6 +312,7 @@ def run_workload(args, full, B, rank, world, roofline=True):
     if roofline and graphed is None:
         keep = model.overlap_wgrad
         model.overlap_wgrad = False
+        model.time_comm = False
         probe = ops.LaunchTimer(kinds=tuple(args.timer_kinds.split(",")))
         ops.TIMER = probe
         step()
@@ -322,8 +335,12 @@ def run_workload(args, full, B, rank, world, roofline=True):
         dt = float(tt)
     res = {"value": round(B * world * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 3),
            "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3), "final_total_loss": float(bl["total"].detach()),
-           "side_streams": int(model._ov) if not args.serial_streams else 0,
+           "side_streams": ov_timed,
            "workload": workload_name(args, full, B), "batch_per_gpu": B}
+    if comm_ms:
+        res["exposed_comm_ms_per_step"] = {k: round(sum(c[k] for c in comm_ms) / len(comm_ms), 3) for k in ("grads", "bn")}
+    elif world > 1:
+        res["exposed_comm_ms_per_step"] = None
     if timer is not None:
         summ = timer.summary()
         if summ:
@@ -374,8 +391,42 @@ def precision_text(p):
             f"{PRODUCTS[p]} cross product(s) on v_mfma_f32_32x32x16_bf16" + tail)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a torchrun environment: this process only launches -- it starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a child (one rank process per
+    GPU, RCCL), relays rank 0's JSON line to stdout and exits with the child's status.  It makes no GPU call itself (importing
+    torch does not initialise the device) and never replaces its own process image."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this image
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout:  # rank 0 prints exactly one JSON line; anything else a library wrote to stdout goes to stderr
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    elif rc == 0:
+        rc = 1
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     # stdout carries exactly ONE line (the JSON): whatever libraries print while the job runs (RCCL's version banner,
     # gloo's connection messages, ...) is sent to stderr instead -- file descriptor 1 is pointed at stderr until the end
     sys.stdout.flush()
@@ -388,6 +439,12 @@ def main():
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     ops.set_precision(args.precision)
     B = args.batch
+    backend, ranks_seen = "none", 1
+    if world > 1:
+        backend = torch.distributed.get_backend()
+        ones = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(ones)  # every rank contributes 1: the number of ranks the collective really spans
+        ranks_seen = int(ones.item())
     head = run_workload(args, args.full, B, rank, world, roofline=not args.no_roofline)
 
     if rank == 0:
@@ -406,10 +463,16 @@ def main():
                                    1: "2 HIP streams (weight gradients beside the main chain: chosen from 8192 batch x window rows)",
                                    0: "one stream (serialised: chosen below 8192 batch x window rows, or --serial-streams)"}[int(head["side_streams"])],
                        "precision": precision_text(args.precision),
+                       "side_streams": int(head["side_streams"]),
                        "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
                        "parallelism": f"dp{world}" + ("" if world == 1 else ("+syncbn" if args.sync_bn else "+localbn")),
+                       "backend": {"nccl": "nccl (RCCL)"}.get(backend, backend), "ranks_seen": ranks_seen,
+                       "bn": "single rank" if world == 1 else ("sync" if args.sync_bn else "local"),
                        "final_total_loss": head["final_total_loss"]},
         }
+        if world > 1:
+            # time the main stream of rank 0 waited for collectives, per step (HIP events; the rest of the exchange ran under compute)
+            out["config"]["exposed_comm_ms_per_step"] = head["exposed_comm_ms_per_step"]
         if "roofline" in head:
             out["roofline"] = head["roofline"]
         # every GPU measurement runs BEFORE any CPU baseline: the oracle's 16 intra-op threads keep spinning for a while after their

@@ -131,7 +131,8 @@ int svae_conv_dgrad_split(const svae_conv_desc* d, const float* dy, const void* 
 /* The same launch when dx is the gradient with respect to the OUTPUT of a BatchNorm1d + PReLU / Tanh stage (the `add` / `residual.1-2`
  * pairs of residual.py:88-89,112-113,146-147,173-174) whose saved input is f->x ([rows][ld_in], the layout of dx): the first pass of that
  * stage's backward -- (sum du, sum du * xhat) per channel and the PReLU slope's partial, what svae_affine_prelu_bwd_partial computes
- * from a re-read of dx and x -- comes out of the epilogue: part[tile][2][c_in], dalpha_part[tile * col_blocks + col_block], with
+ * from a re-read of dx and x -- comes out of the epilogue: part[tile][2][c_in], dalpha_part[2 * (tile * col_blocks + col_block)] =
+ * the (hi, lo) float pair of the tile's fp64 slope partial (2 * tiles * col_blocks floats), with
  * svae_conv_dgrad_stats_tiles(d, &col_blocks) row tiles.  scale / shift (and mean / rstd) NULL: bare activation; alpha NULL: tanh.
  * With accumulate the sums are those of the accumulated value (the launch that writes dx last carries them). */
 typedef struct {
@@ -194,7 +195,9 @@ int svae_bn_eval_coeffs(int C, const float* gamma, const float* beta, float eps,
 int svae_affine_prelu_fwd(const float* x, const float* scale, const float* shift, const float* alpha,
                           float* y, long long rows, int C, int ld, void* stream);
 /* backward, pass 1: partial column sums  part[n_chunks][2][C] = (sum du, sum du*xhat),
- * dalpha_part[n_chunks] = sum dy*u*[u<=0]; du = dy*(u>0?1:alpha), u = x*scale+shift. */
+ * dalpha_part[2 * (chunk * ceil(C/64) + column block)] = (hi, lo) float pair of sum dy*u*[u<=0] formed in fp64 (the slope's gradient
+ * sums ~1e6 cancelling terms; 2 * n_chunks * ceil(C/64) floats; the reduction calls below sum all n_parts floats in fp64);
+ * du = dy*(u>0?1:alpha), u = x*scale+shift. */
 int svae_affine_prelu_bwd_partial(const float* dy, const float* x, const float* scale, const float* shift,
                                   const float* mean, const float* rstd, const float* alpha,
                                   long long rows, int C, int ld, float* part, float* dalpha_part,

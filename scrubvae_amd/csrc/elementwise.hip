@@ -242,13 +242,14 @@ __global__ __launch_bounds__(256) void affine_prelu_fwd_kernel(const float* __re
   }
 }
 
-// backward pass 1: part[chunk][2][C] = (sum du, sum du*xhat); dalpha_part[chunk*gridDim.y + by]
+// backward pass 1: part[chunk][2][C] = (sum du, sum du*xhat); dalpha_part[2 * (chunk*gridDim.y + by)] = (hi, lo) of the block's
+// slope partial, formed from fp64 products and sums (the slope's gradient is a sum of ~1e6 cancelling terms)
 __global__ __launch_bounds__(256) void affine_prelu_bwd_partial_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ alpha, long long rows, int C, int ld,
     float* __restrict__ part, float* __restrict__ dalpha_part) {
   __shared__ float red[2][16][65];
-  __shared__ float red4[4];
+  __shared__ double red4[4];
   const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.y * 64 + c4 * 4;
   const long long r0 = (long long)blockIdx.x * STAT_ROWS;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_partial_kernel(
   const bool th = alpha == nullptr;
   const float a = th ? 0.f : alpha[0];
   float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-  float da = 0.f;
+  double da = 0.0;
   if (c < C) {
     float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
     if (scale != nullptr) {
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_partial_kernel(
       for (int k = 0; k < 4; ++k) {
         const float u = xv[k] * sc[k] + sh[k];
         const float du = dv[k] * act_grad(u, a, th);
-        if (!th && !(u > 0.f)) da += dv[k] * u;
+        if (!th && !(u > 0.f)) da += (double)dv[k] * (double)u;
         s0[k] += du;
         s1[k] += du * (xv[k] - mu[k]) * rs[k];
       }
@@ -294,8 +295,16 @@ __global__ __launch_bounds__(256) void affine_prelu_bwd_partial_kernel(
     const int col = blockIdx.y * 64 + cc;
     if (col < C) part[((long long)blockIdx.x * 2 + k) * C + col] = t;
   }
-  const float tot = block_sum_256(da, red4);
-  if (threadIdx.x == 0) dalpha_part[(long long)blockIdx.x * gridDim.y + blockIdx.y] = tot;
+  da = wave_sum_d(da);
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = da;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = (red4[0] + red4[1]) + (red4[2] + red4[3]);
+    const float hi = (float)tot;
+    float* o = dalpha_part + 2 * ((long long)blockIdx.x * gridDim.y + blockIdx.y);
+    o[0] = hi;
+    o[1] = (float)(tot - (double)hi);
+  }
 }
 
 // backward pass 2
@@ -685,7 +694,7 @@ __global__ void adam_advance_kernel(float* __restrict__ hyper, float b1, float b
 __global__ __launch_bounds__(256) void clip_grads_kernel(float* __restrict__ g, long long n, const float* __restrict__ sumsq,
                                                           float max_norm) {
   const float coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
-  if (!(coef < 1.f)) return;
+  if (coef >= 1.f) return;  // a NaN norm falls through and poisons every gradient, as torch's clamp(NaN, max=1) * g does
   const long long n4 = n / 4;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float4 v = ld4(g + i * 4);

@@ -413,11 +413,12 @@ static long long ws_floats(const EnsArgs& a, int n_members) {
 }
 
 template <typename K>
-static int set_lds(K kernel, bool& done, const char* what) {
-  if (!done) {
+static int set_lds(K kernel, DeviceOnce& once, const char* what) {
+  int dev;
+  if (once.need(&dev)) {  // per device: the attribute belongs to the current device's copy of the kernel
     const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SVAE_REQUIRE(e == hipSuccess, SVAE_ERR_LAUNCH, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", what, hipGetErrorString(e));
-    done = true;
+    once.done(dev);
   }
   return SVAE_OK;
 }
@@ -430,7 +431,7 @@ extern "C" int svae_ens_fwd(const svae_ens_desc* d, void* stream) {
   EnsArgs a;
   size_t smem = 0;
   if (int e = build(d, a, false, &smem)) return e;
-  static bool attr = false;
+  static DeviceOnce attr;
   if (int e = set_lds(ens_fwd_kernel, attr, "ens_fwd")) return e;
   hipLaunchKernelGGL(ens_fwd_kernel, dim3(a.tiles, d->n_members), dim3(ENS_THREADS), smem, (hipStream_t)stream, a);
   return check_launch("ens_fwd");
@@ -452,7 +453,7 @@ extern "C" int svae_ens_bwd(const svae_ens_desc* d, float* d_src0, int ld_d, flo
                "ens_bwd: workspace too small (need %zu B)", (size_t)ws_floats(a, d->n_members) * sizeof(float));
   SVAE_REQUIRE(!d_src0 || ld_d >= d->n0, SVAE_ERR_ARG, "ens_bwd: ld of d_src0 %d < %d", ld_d, d->n0);
   a.ws = (float*)ws;
-  static bool attr = false;
+  static DeviceOnce attr;
   if (int e = set_lds(ens_bwd_kernel, attr, "ens_bwd")) return e;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ens_bwd_kernel, dim3(a.tiles, d->n_members), dim3(ENS_THREADS), smem, st, a);

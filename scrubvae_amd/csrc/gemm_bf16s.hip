@@ -148,7 +148,7 @@ __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)
                                               int tile_y = 0) {
   if (tile_x < 0) { tile_x = blockIdx.x; tile_y = blockIdx.y; }  // (row tile, column tile) of this workgroup
   float cs[NT], cq[NT];
-  float da = 0.f;
+  double da = 0.0;  // the PReLU slope's partial: a sum of ~1e6 cancelling terms over the launch -- fp64 products and sums
   const bool bwd = g.bn_x != nullptr;        // uniform
   const bool th = g.bn_alpha == nullptr;     // tanh instead of PReLU
   const float slope = (bwd && !th) ? g.bn_alpha[0] : 0.f;
@@ -180,7 +180,7 @@ __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)
             const float u = x * sc + sh;
             float du;
             if (th) { const float t = tanhf(u); du = v * (1.f - t * t); }
-            else { du = u > 0.f ? v : slope * v; if (!(u > 0.f)) da += v * u; }
+            else { du = u > 0.f ? v : slope * v; if (!(u > 0.f)) da += (double)v * (double)u; }
             cs[nt] += du;
             cq[nt] += du * (x - mu) * rs;
           } else {
@@ -206,10 +206,10 @@ __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)
       red[(1 * WR + wr) * BN + c] = cq[nt];
     }
   }
-  float* dred = red + 2 * WR * BN;  // one slot per wave for the slope partial
+  float* dred = red + 2 * WR * BN;  // one (hi, lo) slot per wave for the slope partial
   if (bwd && g.bn_dalpha) {
-    da = wave_sum(da);
-    if ((tid & 63) == 0) dred[tid >> 6] = da;
+    da = wave_sum_d(da);
+    if ((tid & 63) == 0) { const float hi = (float)da; dred[2 * (tid >> 6)] = hi; dred[2 * (tid >> 6) + 1] = (float)(da - (double)hi); }
   }
   __syncthreads();
   for (int i = tid; i < 2 * BN; i += nth) {
@@ -219,10 +219,13 @@ __device__ __forceinline__ void tile_epilogue(const GatherArgs& g, f32x16 (&acc)
     for (int w = 0; w < WR; ++w) t += red[(k * WR + w) * BN + c];
     if (n0 + c < g.N) g.stats[((long long)tile_x * 2 + k) * g.N + n0 + c] = t;
   }
-  if (bwd && g.bn_dalpha && tid == 0) {
-    float t = 0.f;
-    for (int w = 0; w < nth / 64; ++w) t += dred[w];
-    g.bn_dalpha[(long long)tile_x * gridDim.y + tile_y] = t;
+  if (bwd && g.bn_dalpha && tid == 0) {  // the tile's partial leaves as a (hi, lo) float pair: the reduction kernels sum partials in fp64
+    double t = 0.0;
+    for (int w = 0; w < nth / 64; ++w) t += (double)dred[2 * w] + (double)dred[2 * w + 1];
+    const float hi = (float)t;
+    float* o = g.bn_dalpha + 2 * ((long long)tile_x * gridDim.y + tile_y);
+    o[0] = hi;
+    o[1] = (float)(t - (double)hi);
   }
 }
 
@@ -2469,7 +2472,7 @@ __device__ __forceinline__ void tile_epilogue16(const GatherArgs& g, f32x4v (&ac
                                                 int lane, float* red, int tid, int nth, float oscale, int tile_x, int tile_y) {
   const int l16 = lane & 15, rg = lane >> 4;
   float cs[NBK], cq[NBK];
-  float da = 0.f;
+  double da = 0.0;  // the PReLU slope's partial: a sum of ~1e6 cancelling terms over the launch -- fp64 products and sums
   const bool bwd = g.bn_x != nullptr;        // uniform
   const bool th = g.bn_alpha == nullptr;     // tanh instead of PReLU
   const float slope = (bwd && !th) ? g.bn_alpha[0] : 0.f;
@@ -2501,7 +2504,7 @@ __device__ __forceinline__ void tile_epilogue16(const GatherArgs& g, f32x4v (&ac
             const float u = x * sc + sh;
             float du;
             if (th) { const float t = tanhf(u); du = v * (1.f - t * t); }
-            else { du = u > 0.f ? v : slope * v; if (!(u > 0.f)) da += v * u; }
+            else { du = u > 0.f ? v : slope * v; if (!(u > 0.f)) da += (double)v * (double)u; }
             cs[nb] += du;
             cq[nb] += du * (x - mu) * rs;
           } else {
@@ -2529,10 +2532,10 @@ __device__ __forceinline__ void tile_epilogue16(const GatherArgs& g, f32x4v (&ac
       red[(1 * WR + wr) * BN + c] = cq[nb];
     }
   }
-  float* dred = red + 2 * WR * BN;  // one slot per wave for the slope partial
+  float* dred = red + 2 * WR * BN;  // one (hi, lo) slot per wave for the slope partial
   if (bwd && g.bn_dalpha) {
-    da = wave_sum(da);
-    if ((tid & 63) == 0) dred[tid >> 6] = da;
+    da = wave_sum_d(da);
+    if ((tid & 63) == 0) { const float hi = (float)da; dred[2 * (tid >> 6)] = hi; dred[2 * (tid >> 6) + 1] = (float)(da - (double)hi); }
   }
   __syncthreads();
   for (int i = tid; i < 2 * BN; i += nth) {
@@ -2542,10 +2545,13 @@ __device__ __forceinline__ void tile_epilogue16(const GatherArgs& g, f32x4v (&ac
     for (int w = 0; w < WR; ++w) t += red[(k * WR + w) * BN + c];
     if (n0 + c < g.N) g.stats[((long long)tile_x * 2 + k) * g.N + n0 + c] = t;
   }
-  if (bwd && g.bn_dalpha && tid == 0) {
-    float t = 0.f;
-    for (int w = 0; w < nth / 64; ++w) t += dred[w];
-    g.bn_dalpha[(long long)tile_x * gridDim.y + tile_y] = t;
+  if (bwd && g.bn_dalpha && tid == 0) {  // the tile's partial leaves as a (hi, lo) float pair: the reduction kernels sum partials in fp64
+    double t = 0.0;
+    for (int w = 0; w < nth / 64; ++w) t += (double)dred[2 * w] + (double)dred[2 * w + 1];
+    const float hi = (float)t;
+    float* o = g.bn_dalpha + 2 * ((long long)tile_x * gridDim.y + tile_y);
+    o[0] = hi;
+    o[1] = (float)(t - (double)hi);
   }
 }
 

@@ -552,13 +552,14 @@ extern "C" int svae_pose_tail(const float* y, int ld, const float* offsets, cons
   const int tr = tail_rows();
   const size_t smem = (size_t)(tr * g.ldt + 2 * tr * g.ldo + tr * 9 + SVAE_MAX_CHAINS) * sizeof(float);
   SVAE_REQUIRE(smem <= 160 * 1024, SVAE_ERR_SHAPE, "pose_tail: LDS tile %zu B exceeds 160 KiB", smem);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  int attr_dev;
+  if (attr_set.need(&attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)pose_tail_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pose_tail_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pose_tail_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SVAE_REQUIRE(e == hipSuccess, SVAE_ERR_LAUNCH, "pose_tail: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(e));
-    attr_set = true;
+    attr_set.done(attr_dev);
   }
   const dim3 grid(svae_tail_blocks(rows)), block(64 * n_waves);
   if (tr == 64) hipLaunchKernelGGL(pose_tail_kernel<64>, grid, block, smem, (hipStream_t)stream, g);

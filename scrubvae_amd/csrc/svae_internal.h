@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include "../../include/scrubvae_hip.h"
 
 namespace svae {
@@ -19,6 +20,19 @@ inline int check_launch(const char* what) {
   return SVAE_OK;
 }
 
+// Per-device "done once" flag for settings that belong to the current device's copy of a kernel (hipFuncSetAttribute):
+// bit d = done on device d.  The guarded action is idempotent, so two threads racing through the first call are harmless.
+struct DeviceOnce {
+  std::atomic<unsigned long long> bits{0};
+  bool need(int* dev_out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    *dev_out = dev;
+    return dev >= 64 || !(bits.load(std::memory_order_acquire) & (1ull << dev));
+  }
+  void done(int dev) { if (dev < 64) bits.fetch_or(1ull << dev, std::memory_order_release); }
+};
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define SVAE_REQUIRE(cond, code, ...)      \
@@ -31,6 +45,12 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // ---- device helpers ---------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;

@@ -184,8 +184,15 @@ class ResVAE(nn.Module):
         self.bucket_min_bytes = 4 << 20  # smallest encoder gradient bucket worth its own all-reduce (xGMI: few, large)
         self.sync_bn = True
         self.shuffle_seed, self._shuffle_draws = 0, 0  # shared-seed global permutation of the adversarial shuffle (N > 1)
+        # bench.py: HIP events (on the main stream) around every point where the main chain waits for a collective -- the
+        # sync-BatchNorm statistics and the tail of the gradient exchange; what they bracket is the EXPOSED communication time
+        self.time_comm, self._comm_events = False, []
         # training fast path: skip the forward-time tail launch; data_o["x6d"/"root"] are then
         # only valid after get_batch_loss (which runs the fused tail once).  Off by default.
+        # Contract of the fast path: get_batch_loss may already write (or, with accumulate_grads, add) the scrubber heads'
+        # parameter gradients into flat_grads, beside the tail; between get_batch_loss and total.backward() the caller may
+        # re-bind gradients (`param.grad = None`, the reference loop) but must not zero them in place
+        # (`optimizer.zero_grad(set_to_none=False)`), and every get_batch_loss must be followed by exactly one backward.
         self.defer_tail = False
         self._tail_done = True
         # weight-gradient GEMMs / skip branches on side streams, concurrent with the main chain.  None = decide per pass from the
@@ -335,6 +342,8 @@ class ResVAE(nn.Module):
         the split-bf16 weight copies of every conv seen so far are refreshed in one launch (convs met for
         the first time in this pass split lazily at their first use)."""
         self.__dict__["_main"] = None
+        if self.time_comm and self.training:
+            self._comm_events.append([])
         ops.check_current_device(self.device)
         ops.bump_weight_epoch()
         if self._split_users:
@@ -464,6 +473,38 @@ class ResVAE(nn.Module):
             return dist.all_reduce(t, group=self.process_group, async_op=async_op)
         return None
 
+    def _comm_bracket(self, kind):
+        """Context manager: with `time_comm` set, records a pair of timing events on the main stream around the enclosed
+        collective(s) -- the time the main chain spends waiting for the exchange (kind: "bn" | "grads")."""
+        import contextlib
+        if not self.time_comm:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def bracket():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self._main_stream())
+            yield
+            e1.record(self._main_stream())
+            if not self._comm_events:
+                self._comm_events.append([])
+            self._comm_events[-1].append((kind, e0, e1))
+        return bracket()
+
+    def pop_comm_times(self):
+        """Per optimizer step since the last call: {"grads": ms, "bn": ms} the main stream waited for collectives (needs
+        `time_comm`; synchronises the device)."""
+        torch.cuda.synchronize(self.device)
+        out = []
+        for step in self._comm_events:
+            d = {"grads": 0.0, "bn": 0.0}
+            for kind, e0, e1 in step:
+                d[kind] += e0.elapsed_time(e1)
+            if step:
+                out.append(d)
+        self._comm_events = []
+        return out
+
     def _allgather(self, t):
         """Concatenation of the ranks' 1-D tensors `t` in rank order (same length on every rank)."""
         import torch.distributed as dist
@@ -483,7 +524,7 @@ class ResVAE(nn.Module):
         """The adversarial shuffle's permutation of the GLOBAL batch (AdvNetScrubber.shuffle, disentangle.py:678-684) under data
         parallelism: drawn on the host from a generator every rank seeds identically (shuffle_seed, advanced per draw), so all
         ranks hold the same permutation without a broadcast."""
-        g = torch.Generator().manual_seed(int(self.shuffle_seed) * 1000003 + self._shuffle_draws)
+        g = torch.Generator().manual_seed((int(self.shuffle_seed) * 1000003 + self._shuffle_draws) & 0x7FFFFFFFFFFFFFFF)
         self._shuffle_draws += 1
         return torch.randperm(n, generator=g)
 
@@ -536,7 +577,8 @@ class ResVAE(nn.Module):
                 ops.bn_stats_partial(x, rows, Cp, Cp, part)
             if self.world_size > 1 and self.sync_bn:
                 ops.bn_reduce_partials(part, nch, Cp, sums)
-                self._allreduce(sums)
+                with self._comm_bracket("bn"):
+                    self._allreduce(sums)
                 ops.bn_finalize(sums, rows * self.world_size, Cp, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
                                 bn.running_var, mean, rstd, scale, shift)
                 bn.num_batches_tracked.add_(1)
@@ -560,7 +602,7 @@ class ResVAE(nn.Module):
             return None
         Cp = cv.c_in_p
         part = self._buf(f"bn.tpart.{n}.{Cp}", (n, 2, Cp))
-        dap = self._buf(f"bn.tdap.{n * cb}", (n * cb,))
+        dap = self._buf(f"bn.tdap.{n * cb}", (2 * n * cb,))  # (hi, lo) pair per tile
         f = BnBwdFuse()
         f.x, f.part = x.data_ptr(), part.data_ptr()
         if not bare:
@@ -581,7 +623,7 @@ class ResVAE(nn.Module):
         else:
             nch = ops.bn_chunks(rows)
             part = self._buf(f"bn.part.{nch}.{Cp}", (nch, 2, Cp))
-            dap = self._buf(f"bn.dap.{nch}.{Cp}", (nch * ((Cp + 63) // 64),))
+            dap = self._buf(f"bn.dap.{nch}.{Cp}", (2 * nch * ((Cp + 63) // 64),))  # (hi, lo) pair per block
             ops.affine_prelu_bwd_partial(dy, x, scale, shift, mean, rstd, act.weight, rows, Cp, Cp, part, dap)
         count = rows
         if self.world_size > 1 and self.sync_bn:
@@ -590,7 +632,8 @@ class ResVAE(nn.Module):
             # later); the input gradient needs the global ones
             gl = self._buf(tag + ".dsums_g", (2, Cp))
             gl.copy_(sums)
-            self._allreduce(gl)
+            with self._comm_bracket("bn"):
+                self._allreduce(gl)
             ops.affine_prelu_bwd_apply(dy, x, scale, shift, mean, rstd, bn.weight, act.weight, gl, rows * self.world_size,
                                        dx, rows, Cp, Cp, None, None, slope_grad(act), dap, dap.numel(), acc,
                                        colsum_part=self._dx_colsum_part(tag, dx, rows, Cp))
@@ -738,6 +781,20 @@ class ResVAE(nn.Module):
         y = self._buf("dec.y", (B * self.window, cvo.c_out_p))
         cvo.fwd(d, dec.conv_out.weight, dec.conv_out.bias, y)
         return y
+
+    def _tail_prealloc(self, B, data, with_grad):
+        """Materialises, on the CURRENT stream, every workspace _run_tail may allocate: a first-use torch.zeros / torch.empty
+        inside a forked tail would be queued on torch's current stream while the kernel that reads it runs on the side stream
+        (only the C-ABI launches follow the fork)."""
+        rows, J = B * self.window, self.n_keypts
+        self._buf("out.x6d", (B, self.window, J, 6))
+        if self.arena_size is not None:
+            self._buf("out.root", (B, self.window, 3))
+        self._buf("tail.part", (ops.tail_blocks(rows), 2))
+        if "offsets" not in data or "target_pose" not in data:
+            self._buf("zero.j3", (rows, J, 3), zero=True)
+        if with_grad:
+            self._buf("dec.dy", (rows, pad16(self.in_channels)))
 
     def _run_tail(self, B, data, jpe_scale, root_scale, ext_dx6d, with_grad):
         """Fused tanh/unpack/FK/loss tail.  Without offsets/target in `data` (pure forward)
@@ -1100,7 +1157,7 @@ class ResVAE(nn.Module):
         else:
             nch = ops.bn_chunks(rows)
             part = self._buf(f"bn.part.{nch}.{C0}", (nch, 2, C0))
-            dap = self._buf(f"bn.dap.{nch}.{C0}", (nch * ((C0 + 63) // 64),))
+            dap = self._buf(f"bn.dap.{nch}.{C0}", (2 * nch * ((C0 + 63) // 64),))
             ops.affine_prelu_bwd_partial(g, c0, None, None, None, None, enc.activation.weight, rows, C0, C0, part, dap)
         g_c0 = self._buf("g.enc.c_in", (rows, C0))
         ops.affine_prelu_bwd_apply(g, c0, None, None, None, None, None, enc.activation.weight, None, 1.0, g_c0, rows, C0, C0,
@@ -1114,11 +1171,12 @@ class ResVAE(nn.Module):
         # ---- data-parallel: sum gradients over ranks (losses are normalised by the GLOBAL batch)
         if self.world_size > 1:  # what is left: conv_in + the blocks below the last bucket, and everything after the decoder
             hi = self._dec_span[1]
-            if enc_cut > 0:
-                self._allreduce(self.flat_grads[:enc_cut])
-            if hi < self.flat_grads.numel():
-                self._allreduce(self.flat_grads[hi:])
-            for w in works:
-                if w is not None:
-                    w.wait()
+            with self._comm_bracket("grads"):
+                if enc_cut > 0:
+                    self._allreduce(self.flat_grads[:enc_cut])
+                if hi < self.flat_grads.numel():
+                    self._allreduce(self.flat_grads[hi:])
+                for w in works:
+                    if w is not None:
+                        w.wait()
         self._pending = None

@@ -61,6 +61,14 @@ def attach(model, process_group=None, sync_bn=True, broadcast=True):
         for m in mods.values():
             if hasattr(m, "process_group"):
                 m.process_group = process_group
+    if model.world_size > 1:
+        # seed of the shared adversarial-shuffle permutation stream (ResVAE.global_permutation): rank 0's torch seed, so that a
+        # run's shuffles follow the user's torch.manual_seed like the single-rank torch.randperm does
+        seed = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFF], dtype=torch.int64)
+        if dist.get_backend(process_group) == "nccl":
+            seed = seed.to(model.device)
+        dist.broadcast(seed, src=0, group=process_group)
+        model.shuffle_seed = int(seed.item())
     if broadcast and model.world_size > 1:
         dist.broadcast(model.flat_params, src=0, group=process_group)
         for b in model.buffers():

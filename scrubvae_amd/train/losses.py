@@ -102,6 +102,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
 
     fork_tail = model._ov == 2 and _TAIL_FORK
     if fork_tail:
+        model._tail_prealloc(B, dev_data, train)  # first-use allocations / zero fills happen on the main stream, before the fork
         model._fork(_tail, k=1)
     else:
         _tail()

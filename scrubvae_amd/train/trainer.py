@@ -107,12 +107,16 @@ class FusedAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,
+                # position in the data-parallel adversarial-shuffle stream (ResVAE.global_permutation): a resumed run continues it
+                "shuffle": [int(self.model.shuffle_seed), int(self.model._shuffle_draws)],
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
+        if "shuffle" in sd:
+            self.model.shuffle_seed, self.model._shuffle_draws = int(sd["shuffle"][0]), int(sd["shuffle"][1])
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
 

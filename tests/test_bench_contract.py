@@ -52,6 +52,9 @@ def test_bench_prints_exactly_one_json_line_with_the_contract_fields():
     assert cb["elbo_match"]["ok"] is True and cb["elbo_match"]["batch"] == 64   # checked at the timed batch
     assert cb["threads"] == cb["cores"] and cb["host_cores"] >= cb["threads"]
     assert "configs[2]" in d["config"]["workload"] and "secondary" not in d       # secondary only accompanies the default batch
+    c = d["config"]
+    assert c["ranks_seen"] == 1 and c["backend"] == "none" and c["bn"] == "single rank"
+    assert c["side_streams"] == 0 and c["streams"].startswith("one stream")       # 64 x 64 rows: the serial schedule was timed
 
 
 @pytest.mark.gpu
@@ -74,7 +77,62 @@ def test_bench_two_ranks_full_config_sync_bn():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2+syncbn"
+    assert d["config"]["ranks_seen"] == 2 and d["config"]["bn"] == "sync" and d["config"]["exposed_comm_ms_per_step"]["bn"] > 0
     assert "configs[2]" in d["config"]["workload"] and "cpu_baseline" not in d and "secondary" not in d
     assert abs(d["value"] - 128 * 2 / (d["ms_per_step"] * 2e-3)) <= 0.01 * d["value"]
     import math
     assert math.isfinite(d["config"]["final_total_loss"])
+
+
+def test_bench_plain_command_becomes_a_launcher_without_touching_the_gpu(monkeypatch, capsys):
+    """`python bench.py --gpus N` outside a torchrun environment starts N rank processes through torch.distributed.run as a CHILD
+    (never exec), relays rank 0's JSON line and returns the child's status -- checked with the child process faked."""
+    sys.path.insert(0, ROOT)
+    import subprocess as sp
+
+    import bench
+    seen = {}
+
+    class FakePopen:
+        def __init__(self, cmd, stdout=None, env=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = iter(["NCCL version banner\n", '{"metric": "m", "value": 1.0, "n_gpus": 4}\n'])
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(sp, "Popen", FakePopen)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    import torch
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("the launcher made a GPU call")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "m", "value": 1.0, "n_gpus": 4}' and "NCCL version banner" in out.err
+
+
+@pytest.mark.gpu
+def test_bench_plain_command_line_two_ranks():
+    """Exactly what the driver types -- `python bench.py --gpus 2 ...`, no torchrun -- on the one GPU of the test box (two gloo
+    ranks): the bench launches its own ranks and the line records what the collective really spanned."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=ROOT, SVAE_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["backend"] == "gloo" and c["bn"] == "local"
+    assert c["global_batch"] == 128 and c["parallelism"] == "dp2+localbn"
+    ex = c["exposed_comm_ms_per_step"]
+    assert ex["grads"] > 0 and ex["bn"] == 0      # per-rank BatchNorm statistics: no BatchNorm collective
+    assert "roofline" in d and "cpu_baseline" not in d
+    assert c["streams"].startswith("one stream") == (c["side_streams"] == 0)

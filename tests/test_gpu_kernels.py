@@ -148,7 +148,7 @@ def test_bn_prelu_fwd_bwd(ops, rows, Cc):
     assert relerr(rmd.cpu(), rm) < 5e-6 and relerr(rvd.cpu(), rv) < 5e-6
 
     dyd = dev(dy)
-    dap = torch.empty(nch * ((Cc + 63) // 64), device="cuda")
+    dap = torch.empty(2 * nch * ((Cc + 63) // 64), device="cuda")
     ops.affine_prelu_bwd_partial(dyd, xd, scale, shift, mean, rstd, ad, rows, Cc, Cc, part, dap)
     ops.bn_reduce_partials(part, nch, Cc, sums)
     dxd = torch.empty_like(xd)
@@ -209,7 +209,7 @@ def test_bn_tanh_fwd_bwd(ops, rows, Cc):
     yd = torch.empty_like(xd)
     ops.affine_prelu_fwd(xd, scale, shift, None, yd, rows, Cc, Cc)
     assert relerr(yd.cpu(), y.detach()) < 5e-6
-    dap = torch.empty(nch * ((Cc + 63) // 64), device="cuda")
+    dap = torch.empty(2 * nch * ((Cc + 63) // 64), device="cuda")
     ops.affine_prelu_bwd_partial(dyd, xd, scale, shift, mean, rstd, None, rows, Cc, Cc, part, dap)
     ops.bn_reduce_partials(part, nch, Cc, sums)
     dxd = torch.empty_like(xd)
@@ -235,7 +235,7 @@ def test_bare_prelu_bwd(ops):
     assert relerr(yd.cpu(), y.detach()) < 1e-6
     nch = ops.bn_chunks(rows)
     part = torch.empty(nch, 2, Cc, device="cuda")
-    dap = torch.empty(nch, device="cuda")
+    dap = torch.empty(2 * nch * ((Cc + 63) // 64), device="cuda")
     ops.affine_prelu_bwd_partial(dyd, xd, None, None, None, None, ad, rows, Cc, Cc, part, dap)
     dxd = torch.empty_like(xd)
     da = torch.zeros(1, device="cuda")

@@ -171,7 +171,8 @@ def test_three_steps_and_eval(golden_dir, name):
 
 def test_oracle_parity_seeded_j23():
     """BASELINE's synthetic 23-joint skeleton, default channels, B=16: HIP vs CPU oracle on the
-    same seeded inputs (no reference fixture exists for J=23: the reference ships 18 joints)."""
+    same seeded inputs (the reference's own outputs on this skeleton are the `vanilla_default_j23_B4` / `full_j23_tiny` fixtures,
+    generated by passing the 23-joint tree through the real reference: test_step0_matches_reference_fixture)."""
     from scrubvae_amd.train.losses import get_batch_loss
     cfg = O.OracleConfig(n_keypts=23, window=64, z_dim=32, kernel=5, diag=True, arena_size=ARENA,
                          kinematic_tree=O.skeleton_tree(23))
@@ -198,7 +199,7 @@ def test_oracle_parity_seeded_j23():
         assert dd < 2e-2, (n, dd)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x6w3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6w3", "f16x3b3", "bf16x6b3"])
 def test_oracle_parity_config5_wide_w256(precision):
     """BASELINE configs[4] at its full widths (window 256, six residual blocks, channels 64..4096, 23 joints; 293 M
     parameters), B=4 so that the CPU oracle finishes in seconds: HIP vs oracle on seeded inputs.  The reference cannot
