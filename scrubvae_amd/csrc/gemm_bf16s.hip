@@ -2001,8 +2001,10 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
 // conv:             S = X (m = c_in),  F = dY (n = c_out), D_t = dW_t;
 // transposed conv:  S = dY (m = c_out), F = X (n = c_in),  D_t = dW_t^T (TRANS_OUT: the epilogue stores the transpose).
 // A tap that leaves its sample (0 <= j ss + t dil - pad < Ls violated) reads a zero region instead of the image: the mask is an
-// address select, no VALU work on fragments.  Requires contiguous geometry (Ls == nj ss, Lf == nj: every conv of the model except
-// the odd-length stride-2 transposed convs, which keep wgrad_gemm_bf16s_kernel), two bf16 pieces, T <= TMAX.
+// address select, no VALU work on fragments.  Geometry: Lf == nj and Ls == nj ss + e -- e = 0 for the contiguous convs, e = 1 for the
+// (k+1)-tap skip convs behind the upsampler (input 2L, output 2L - 1), e = -1 for the odd-length stride-2 (transposed) convs: the
+// image of a stage is still one contiguous run of S rows, and a fragment row's image row moves by e per sample boundary between
+// the stage's first row and it (g.e, g.srows).  Two bf16 pieces, T <= TMAX.
 // Wave tile 32 (m) x WN (n) x T taps: T x NT accumulators of 32 x 32 (T = 5, NT = 2: 160 VGPRs).
 // LDS images: 64-byte chunks (32 channels) of a row XOR-swizzled by the row so that the 4 rows x 64 bytes a half-wave's transposing
 // read touches lie on different banks.
@@ -2052,13 +2054,15 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
   // accumulators alone take 160 of the 256 registers.
   float4 sv[S_ITEMS], fv[F_ITEMS];
   auto load_s = [&](int kt) {
-    const long long srow0 = (r_begin + (long long)kt * KS) * g.ss - g.pad;
+    const long long rk = r_begin + (long long)kt * KS;
+    long long srow0 = rk * g.ss - g.pad;
+    if (g.e != 0) srow0 += (rk / g.nj) * g.e;  // samples are Ls = nj ss + e rows apart: the image starts at the stage's first sample offset
 #pragma unroll
     for (int i = 0; i < S_ITEMS; ++i) {
       const int idx = tid + NTH * i, row = idx / (BM / 4), cq = idx % (BM / 4);
       const long long sr = srow0 + row;
       // (select on the POINTER: a conditional load costs an exec-mask branch and a vmcnt(0) in front of the matrix work)
-      const bool ok = (row < SR) & (sr >= 0) & (sr < g.rowsS) & (c0 + cq * 4 < g.Cs);
+      const bool ok = (row < g.srows) & (sr >= 0) & (sr < g.rowsS) & (c0 + cq * 4 < g.Cs);  // srows = SR + the rows e > 0 adds (<= SR_ALLOC, host-checked)
       sv[i] = *reinterpret_cast<const float4*>(ok ? g.S + sr * g.ldS + c0 + cq * 4 : wgrad_zero_row);
     }
   };
@@ -2107,6 +2111,7 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
   const int a_lane = (wr * 32 + 16 * mhalf + 4 * p4) * 2, f_lane = S_IMG + (wc * WN + 16 * mhalf + 4 * p4) * 2;
   const unsigned njm = (g.nj & (g.nj - 1)) == 0 ? (unsigned)(g.nj - 1) : 0u;  // power-of-two sample length: mask instead of modulo
   int lpos0 = (int)((r_begin + rr0) % g.nj);  // position in its sample of reduction row rr0 of the current stage
+  int sp0 = (int)(r_begin % g.nj);            // ... of the stage's first reduction row (wave-uniform)
 
   f32x16 acc[TMAX][NT];
 #pragma unroll
@@ -2132,6 +2137,9 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
       for (int j = 0; j < 2; ++j) {
         const int rr = ks * 16 + 4 * j + rr0;
         a_base[j] = soff + rr * (SS * RSS) + a_lane;
+        // Ls = nj ss + e (the k+1-tap skip convs: e = 1; odd-length stride-2 (transposed) convs: e = -1): every sample boundary
+        // between the stage's first row and row rr shifts the image row by e
+        if (g.e != 0) a_base[j] += (int)((unsigned)(sp0 + rr) / (unsigned)g.nj) * g.e * RSS;
         f_base[j] = soff + rr * RSF + f_lane;
         // position in the sample of the tap-0 source row, minus the padding: tap t is inside its sample iff 0 <= lbs + t < Ls
         lbs[j] = wrap(lpos0 + ks * 16 + 4 * j) * SS - g.pad;
@@ -2175,6 +2183,7 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
       if (ks == 0) mid(); else tail();
     }
     lpos0 = wrap(lpos0 + KS);  // next stage: the reduction rows advance by KS
+    sp0 = wrap(sp0 + KS);
   };
 
   // stage kt+1 is staged while stage kt is multiplied: S requested before, written between the two k-steps; F requested there,
@@ -2285,12 +2294,14 @@ __global__ __launch_bounds__(512) void wgrad_taps16_bf16s_kernel(const WgradTaps
 
   float4 sv[S_ITEMS], fv[F_ITEMS];
   auto load_s = [&](int kt) {
-    const long long srow0 = (r_begin + (long long)kt * KS) * g.ss - g.pad;
+    const long long rk = r_begin + (long long)kt * KS;
+    long long srow0 = rk * g.ss - g.pad;
+    if (g.e != 0) srow0 += (rk / g.nj) * g.e;  // samples are Ls = nj ss + e rows apart: the image starts at the stage's first sample offset
 #pragma unroll
     for (int i = 0; i < S_ITEMS; ++i) {
       const int idx = tid + NTH * i, row = idx / (BM / 4), cq = idx % (BM / 4);
       const long long sr = srow0 + row;
-      const bool ok = (row < SR) & (sr >= 0) & (sr < g.rowsS) & (c0 + cq * 4 < g.Cs);
+      const bool ok = (row < g.srows) & (sr >= 0) & (sr < g.rowsS) & (c0 + cq * 4 < g.Cs);  // srows = SR + the rows e > 0 adds (<= SR_ALLOC, host-checked)
       sv[i] = *reinterpret_cast<const float4*>(ok ? g.S + sr * g.ldS + c0 + cq * 4 : wgrad_zero_row);
     }
   };
@@ -2334,6 +2345,7 @@ __global__ __launch_bounds__(512) void wgrad_taps16_bf16s_kernel(const WgradTaps
   const int a_lane = (wr * 32 + 4 * p4) * 2, f_lane = S_IMG + (wc * WN + 4 * p4) * 2;
   const unsigned njm = (g.nj & (g.nj - 1)) == 0 ? (unsigned)(g.nj - 1) : 0u;
   int lpos0 = (int)((r_begin + rr0) % g.nj);
+  int sp0 = (int)(r_begin % g.nj);
   auto wrap = [&](int v) { return (int)(njm ? ((unsigned)v & njm) : ((unsigned)v % (unsigned)g.nj)); };
 
   f32x4v acc[TMAX][MB][NB];
@@ -2359,6 +2371,7 @@ __global__ __launch_bounds__(512) void wgrad_taps16_bf16s_kernel(const WgradTaps
     for (int j = 0; j < 2; ++j) {
       const int rr = 16 * j + rr0;
       a_base[j] = soff + rr * (SS * RSS) + a_lane;
+      if (g.e != 0) a_base[j] += (int)((unsigned)(sp0 + rr) / (unsigned)g.nj) * g.e * RSS;  // see wgrad_taps_bf16s_kernel
       f_base[j] = soff + rr * RSF + f_lane;
       lbs[j] = wrap(lpos0 + 16 * j) * SS - g.pad;
     }
@@ -2397,6 +2410,7 @@ __global__ __launch_bounds__(512) void wgrad_taps16_bf16s_kernel(const WgradTaps
     if constexpr (TMAX > 5) tap(std::integral_constant<int, 5>{});
     tail();
     lpos0 = wrap(lpos0 + KS);
+    sp0 = wrap(sp0 + KS);
   };
 
   load_s(0);

@@ -176,6 +176,8 @@ struct WgradTapsArgs {
   int nj, Ls, ss, dil, pad, T;
   int Cs, Cf, ldS, ldF, ldW;
   int accumulate, xmap;
+  int e;       // Ls - nj ss: rows a sample of S has beyond the contiguous geometry (0, +1: skip convs, -1: odd-length stride-2 convs)
+  int srows;   // image rows of a stage: (32 - 1) ss + T + max(e, 0) * (sample boundaries a stage can cross)
 };
 int launch_wgrad_taps(const WgradTapsArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int trans_out, int m16);
 // split-bf16 weight-gradient main kernel (gemm_bf16s.hip); same grid / slabs as wgrad_gemm_kernel

@@ -1142,10 +1142,21 @@ static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float*
   const int wvariant = d->tile[2] / 1000000;
   if (pieces > 0 && (wvariant & 4)) {
     const int Ls = d->transposed ? d->l_out : d->l_in;
-    SVAE_REQUIRE(pieces == 2 && d->dilation == 1 && (d->kernel == 5 || d->kernel == 6) && Ls == wg.nj * d->stride, SVAE_ERR_SHAPE,
-                 "conv_wgrad: the all-taps kernel needs 2 pieces, dilation 1, 5 or 6 taps and l == nj * stride");
+    // Ls = nj stride + e: e = 0 contiguous convs, +1 the (k+1)-tap skip convs (2L -> 2L - 1), -1 odd-length stride-2 (transposed) convs.
+    // The stage image (one contiguous run of S rows) grows by e per sample boundary a 32-row stage can cross; it must fit the rows
+    // the kernel allocates (whole staging passes of 512 / (bm / 4) rows).
+    const int e_rows = Ls - wg.nj * d->stride;
+    const int sr_rows = 31 * d->stride + d->kernel, pass_rows = 512 / (wg.bm / 4);
+    const int sr_alloc = (sr_rows + pass_rows - 1) / pass_rows * pass_rows;
+    const int crossings = (wg.nj - 1 + 31) / wg.nj;
+    const int srows = sr_rows + (e_rows > 0 ? e_rows * crossings : 0);
+    SVAE_REQUIRE(pieces == 2 && d->dilation == 1 && (d->kernel == 5 || d->kernel == 6) && srows <= sr_alloc &&
+                 (e_rows >= 0 || (e_rows == -1 && d->stride == 2)), SVAE_ERR_SHAPE,
+                 "conv_wgrad: the all-taps kernel needs 2 pieces, dilation 1, 5 or 6 taps and l = nj * stride + e with a stage image that fits "
+                 "(e = %d, %d of %d rows)", e_rows, srows, sr_alloc);
     WgradTapsArgs a;
     memset(&a, 0, sizeof(a));
+    a.e = e_rows; a.srows = srows;
     a.S = d->transposed ? dy : x; a.F = d->transposed ? x : dy;
     a.R = wg.R; a.rows_per_split = wg.rps; a.nj = wg.nj;
     a.Ls = Ls; a.ss = d->stride; a.dil = d->dilation; a.pad = d->padding; a.T = d->kernel;

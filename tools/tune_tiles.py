@@ -8,7 +8,8 @@ from scrubvae_amd.data import synthetic
 from scrubvae_amd.get import model as get_model
 from scrubvae_amd.train.losses import get_batch_loss
 
-table = dict(ops.TILE_TABLE) if "--keep" in sys.argv else {}
+KEEP = "--keep" in sys.argv
+table = dict(ops.TILE_TABLE) if KEEP else {}
 # --retune fwd@3,dgrad@2: with --keep, drop the entries of these (kind@pieces) prefixes so that they are measured again (new kernel
 # variants joined the candidate list)
 for a in list(sys.argv):
@@ -20,7 +21,7 @@ CONFIG4 = "--config4" in sys.argv  # BASELINE configs[4]: window 256, six blocks
 sys.argv = [a for a in sys.argv if a not in ("--keep", "--config4")]
 WIDE6 = [64, 128, 256, 512, 1024, 2048, 4096]
 DEFAULT = [64, 128, 256, 512, 1024]
-ops.TILE_TABLE = {}
+ops.TILE_TABLE = dict(table) if KEEP else {}  # --keep: only what is missing (or dropped by --retune) is measured
 ops.AUTOTUNE_REPS = 12
 PRECISIONS = sys.argv[1:] or ["f32", "bf16x6", "bf16x6w3", "bf16x6b3"]
 CASES = (((23, 1024, True, 256, WIDE6), (23, 32, False, 256, WIDE6), (23, 32, True, 256, WIDE6), (23, 1024, False, 256, WIDE6)) if CONFIG4 else
