@@ -347,8 +347,7 @@ def run_workload(args, full, B, rank, world, roofline=True):
             kname, s = max(summ.items(), key=lambda kv: kv[1]["ms"])  # the GEMM template instance with the largest total time
             tf = s["flops"] / (s["ms"] * 1e-3) / 1e12
             split_kernel = "bf16s" in kname
-            pm = re.search(r"bf16s\w*<\d+, \d+, (\d)", kname)  # products per multiply of THIS template: its piece count
-            k_products = {3: 6, 2: 3, 1: 1}[int(pm.group(1))] if pm else PRODUCTS[args.precision]
+            k_products = template_products(kname, args.precision)  # matrix-core products per multiply of THIS template
             peak = PEAK_BF16_MFMA_TFLOPS / k_products if split_kernel else PEAK_F32_MFMA_TFLOPS
             res["roofline"] = {
                 "measured": f"second timed region of {args.steps} steps with the side HIP streams serialised "
@@ -370,6 +369,18 @@ def run_workload(args, full, B, rank, world, roofline=True):
     del model, opt, graphed
     torch.cuda.empty_cache()
     return res
+
+
+def template_products(kname, precision):
+    """Matrix-core products per algorithmic multiply of a split-kernel template instance: 6 / 3 / 1 for 3 / 2 / 1 pieces per operand.
+    The piece count is the third template argument of the gather / per-tap weight-gradient kernels; the 12-wave halo kernels and the
+    all-taps weight-gradient kernels are built for two pieces only (their third argument is something else)."""
+    if not ("bf16s" in kname):
+        return 1
+    if kname.startswith(("wgrad_taps", "gather_halo_ws4")):
+        return 3
+    pm = re.match(r"\w+<\d+, \d+, (\d),", kname)
+    return {3: 6, 2: 3, 1: 1}.get(int(pm.group(1)), PRODUCTS[precision]) if pm else PRODUCTS[precision]
 
 
 def precision_text(p):

@@ -404,8 +404,10 @@ int svae_adam_step_dev(float* p, const float* g, float* m, float* v, long long n
                        float grad_scale, void* stream);
 int svae_adam_advance(float* hyper, float beta1, float beta2, void* stream);
 /* torch.nn.utils.clip_grad_norm_ (trainer.py:164): g *= min(1, max_norm / (sqrt(*sumsq) + 1e-6)); sumsq = device scalar
- * holding the sum of squares of ALL gradients.  Returns without touching g when the clip does not bite. */
-int svae_clip_grads(float* g, long long n, const float* sumsq, float max_norm, void* stream);
+ * holding the sum of squares of ALL gradients.  Returns without touching g when the clip does not bite (a NaN norm poisons every
+ * gradient, as torch's clamp(NaN, max=1) * g does).  norm_out (may be NULL): the total norm sqrt(*sumsq), the function's return value
+ * in torch. */
+int svae_clip_grads(float* g, long long n, const float* sumsq, float max_norm, float* norm_out, void* stream);
 
 /* Batched small dense solves for the streaming scrubbers (reference: MovingAvgLeastSquares.forward,
  * src/scrubvae/model/disentangle.py:466-486 -- torch.linalg.solve(Sxx + l2 I, Sxy) twice per step; direct_lsq_loss,
@@ -434,6 +436,14 @@ int svae_sumsq_blocks(long long n);
 int svae_sumsq_partial(const float* x, long long n, float* part, void* stream);
 /* out[0..k) = sum over rows of part[rows][k] in fixed order (fp64 accumulate) * scale */
 int svae_reduce_rows(const float* part, int rows, int k, float scale, float* out, int accumulate, void* stream);
+/* the same with one scale per column (host array scales[k], k <= 8): the jpe and root terms -- summed by one tail launch,
+ * normalised by 1 / (B 3 J) and 1 / B (losses.py:171,216-219) -- in one launch */
+int svae_reduce_rows_scaled(const float* part, int rows, int k, const float* scales, float* out, void* stream);
+/* L6 (losses.py:320-322): out[0] = sum_i weights[i] * terms[i] over the loss terms' device scalars, in index order (fp32, like the
+ * reference's running total); weights = the loss_scale entries on the host, n <= SVAE_MAX_LOSS_TERMS; terms with weight 0 are
+ * skipped as in the reference */
+#define SVAE_MAX_LOSS_TERMS 48
+int svae_loss_total(const float* terms, const float* weights, int n, float* out, void* stream);
 
 /* ----------------------------------------------------------- small elementwise ops --- */
 int svae_relu_fwd(const float* x, float* y, long long n, void* stream);

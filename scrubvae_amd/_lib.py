@@ -143,13 +143,15 @@ SIGNATURES = {
     "svae_adam_step": (I, [P, P, P, P, LL, F, F, F, F, F, I, I, F, P]),
     "svae_adam_step_dev": (I, [P, P, P, P, LL, P, F, F, F, F, I, F, P]),
     "svae_adam_advance": (I, [P, F, F, P]),
-    "svae_clip_grads": (I, [P, LL, P, F, P]),
+    "svae_clip_grads": (I, [P, LL, P, F, P, P]),
     "svae_small_solve": (I, [P, LL, P, P, LL, P, LL, I, I, I, P]),
     "svae_gauss_ll": (I, [P, I, P, P, P, P, I, I, I, P]),
     "svae_kde_mi": (I, [P, I, P, I, P, P, P, I, P, F, F, P, P, I, I, I, I, P]),
     "svae_sumsq_blocks": (I, [LL]),
     "svae_sumsq_partial": (I, [P, LL, P, P]),
     "svae_reduce_rows": (I, [P, I, I, F, P, I, P]),
+    "svae_reduce_rows_scaled": (I, [P, I, I, C.POINTER(F), P, P]),
+    "svae_loss_total": (I, [P, C.POINTER(F), I, P, P]),
     "svae_relu_fwd": (I, [P, P, LL, P]),
     "svae_relu_bwd": (I, [P, P, P, LL, P]),
     "svae_axpy": (I, [F, P, P, LL, P]),
@@ -193,6 +195,7 @@ def last_error():
     return buf.value.decode()
 
 
+MAX_LOSS_TERMS = 48  # include/scrubvae_hip.h SVAE_MAX_LOSS_TERMS
 ERR_SHAPE, ERR_ALIGN, ERR_WORKSPACE, ERR_LAUNCH, ERR_ARG = -1, -2, -3, -4, -5  # include/scrubvae_hip.h svae_status
 
 

@@ -692,8 +692,10 @@ __global__ void adam_advance_kernel(float* __restrict__ hyper, float b1, float b
 // torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (norm + 1e-6)), norm = sqrt(*sumsq).  Every thread reads the scalar; when
 // the clip does not bite (the reference's max_norm = 1e6) the kernel returns without touching the gradients.
 __global__ __launch_bounds__(256) void clip_grads_kernel(float* __restrict__ g, long long n, const float* __restrict__ sumsq,
-                                                          float max_norm) {
-  const float coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+                                                          float max_norm, float* __restrict__ norm_out) {
+  const float norm = sqrtf(sumsq[0]);
+  if (norm_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;  // the total norm clip_grad_norm_ returns
+  const float coef = max_norm / (norm + 1e-6f);
   if (coef >= 1.f) return;  // a NaN norm falls through and poisons every gradient, as torch's clamp(NaN, max=1) * g does
   const long long n4 = n / 4;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -728,6 +730,33 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     __syncthreads();
   }
   if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)(red[0] * (double)scale);
+}
+
+// out[c] = scale[c] * sum over rows of part[rows][k] (k <= 8): reduce_rows_kernel with one scale per column, so that loss terms
+// normalised differently (jpe: 1 / (B 3 J), root: 1 / B; losses.py:171,216-219) leave ONE launch
+struct ColScales { float s[8]; };
+__global__ __launch_bounds__(256) void reduce_rows_scaled_kernel(const float* __restrict__ part, int rows, int k, ColScales sc, float* out) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) s += (double)part[(long long)r * k + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = (float)(red[0] * (double)sc.s[c]);
+}
+
+// total = sum_i w[i] * terms[i] in index order, fp32 like the reference's running `total += scale * loss` (losses.py:320-322)
+struct LossWeights { float w[SVAE_MAX_LOSS_TERMS]; };
+__global__ void loss_total_kernel(const float* __restrict__ terms, LossWeights lw, int n, float* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float t = 0.f;
+  for (int i = 0; i < n; ++i)
+    if (lw.w[i] != 0.f) t += lw.w[i] * terms[i];
+  out[0] = t;
 }
 
 // ------------------------------------------------------------------ small elementwise
@@ -977,9 +1006,9 @@ extern "C" int svae_adam_advance(float* hyper, float beta1, float beta2, void* s
   return check_launch("adam_advance");
 }
 
-extern "C" int svae_clip_grads(float* g, long long n, const float* sumsq, float max_norm, void* stream) {
+extern "C" int svae_clip_grads(float* g, long long n, const float* sumsq, float max_norm, float* norm_out, void* stream) {
   SVAE_REQUIRE(g && sumsq && n > 0 && n % 4 == 0 && max_norm > 0.f, SVAE_ERR_ARG, "clip_grads: bad args");
-  hipLaunchKernelGGL(clip_grads_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, ST(stream), g, n, sumsq, max_norm);
+  hipLaunchKernelGGL(clip_grads_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, ST(stream), g, n, sumsq, max_norm, norm_out);
   return check_launch("clip_grads");
 }
 
@@ -995,6 +1024,23 @@ extern "C" int svae_reduce_rows(const float* part, int rows, int k, float scale,
   SVAE_REQUIRE(part && out && rows > 0 && k > 0, SVAE_ERR_ARG, "reduce_rows: bad args");
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(k), dim3(256), 0, ST(stream), part, rows, k, scale, out, accumulate);
   return check_launch("reduce_rows");
+}
+
+extern "C" int svae_reduce_rows_scaled(const float* part, int rows, int k, const float* scales, float* out, void* stream) {
+  SVAE_REQUIRE(part && out && scales && rows > 0 && k > 0 && k <= 8, SVAE_ERR_ARG, "reduce_rows_scaled: bad args (k <= 8)");
+  ColScales sc;
+  for (int i = 0; i < 8; ++i) sc.s[i] = i < k ? scales[i] : 0.f;
+  hipLaunchKernelGGL(reduce_rows_scaled_kernel, dim3(k), dim3(256), 0, ST(stream), part, rows, k, sc, out);
+  return check_launch("reduce_rows_scaled");
+}
+
+extern "C" int svae_loss_total(const float* terms, const float* weights, int n, float* out, void* stream) {
+  SVAE_REQUIRE(terms && weights && out && n > 0 && n <= SVAE_MAX_LOSS_TERMS, SVAE_ERR_ARG, "loss_total: bad args (n <= %d)",
+               SVAE_MAX_LOSS_TERMS);
+  LossWeights lw;
+  for (int i = 0; i < SVAE_MAX_LOSS_TERMS; ++i) lw.w[i] = i < n ? weights[i] : 0.f;
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, ST(stream), terms, lw, n, out);
+  return check_launch("loss_total");
 }
 
 extern "C" int svae_relu_fwd(const float* x, float* y, long long n, void* stream) {

@@ -133,6 +133,36 @@ class ResidualDecoder(nn.Module):
         self.conv_out = ConvP(ch[0], out_channels, self.final_kernel, 1, 3, transposed=True)
 
 
+class _JointLinear:
+    """fc_mu || fc_sigma[0] as one Linear: the joint weight / bias tensors (views of the flat parameter buffer, `.grad` = the same
+    regions of the flat gradient buffer) with the attributes ResVAE._lin / _wgrad read from a LinearP."""
+
+    def __init__(self, weight, bias, in_lib, out_lib, in_f, out_f):
+        self.weight, self.bias = weight, bias
+        self.in_lib, self.out_lib, self.in_f, self.out_f = in_lib, out_lib, in_f, out_f
+
+
+class _LazyList:
+    """A list evaluated on first use (len / index / iteration): data_o entries nobody may read in a training step."""
+
+    def __init__(self, make):
+        self._make, self._val = make, None
+
+    def _get(self):
+        if self._val is None:
+            self._val, self._make = self._make(), None
+        return self._val
+
+    def __len__(self):
+        return len(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
+
+
 class _TotalLoss(torch.autograd.Function):
     """``batch_loss["total"]``: its backward runs the HIP reverse schedule and fills the
     parameters' ``.grad`` (reference: ``batch_loss["total"].backward()``, trainer.py:163)."""
@@ -217,14 +247,37 @@ class ResVAE(nn.Module):
     # ------------------------------------------------------------------ parameters
     def _materialise(self, device):
         leaves = [(n, m) for n, m in self.named_modules() if isinstance(m, Leaf)]
+        # Joint parameters: fc_mu and fc_sigma[0] (residual.py:219-222) read the same flattened activations, so their weights live
+        # side by side in ONE [1][in][z_p + sig_p] tensor (biases likewise) and each module's parameter is a column slice of it:
+        # the two Linear layers are one GEMM forward, one data-gradient and one weight-gradient launch (module tree, parameter
+        # names, shapes and state_dict unchanged; the slices are ordinary -- non-contiguous -- Parameters).
+        fm, fs = self.encoder.fc_mu, self.encoder.fc_sigma[0]
+        joint = {}  # (id(leaf), pname) -> (joint key, joint shape, axis, start, length)
+        n_mu, n_sig = fm.out_lib, fs.out_lib
+        for leaf, start, length in ((fm, 0, n_mu), (fs, n_mu, n_sig)):
+            joint[(id(leaf), "weight")] = ("heads.w", (1, fm.in_lib, n_mu + n_sig), 2, start, length)
+            joint[(id(leaf), "bias")] = ("heads.b", (n_mu + n_sig,), 0, start, length)
         total = 0
         slots = []
+        regions = {}
         for n, m in leaves:
             for pname, shape in m.specs.items():
+                j = joint.get((id(m), pname))
+                if j is not None:
+                    key, jshape, axis, start, length = j
+                    if key not in regions:
+                        jn = 1
+                        for d in jshape:
+                            jn *= d
+                        regions[key] = (total, jn)
+                        total += (jn + 3) // 4 * 4
+                    off, numel = regions[key]
+                    slots.append((m, pname, shape, off, numel, (jshape, axis, start, length)))
+                    continue
                 numel = 1
-                for s in shape:
-                    numel *= s
-                slots.append((m, pname, shape, total, numel))
+                for d in shape:
+                    numel *= d
+                slots.append((m, pname, shape, total, numel, None))
                 total += (numel + 3) // 4 * 4
         self.flat_params = torch.zeros(total, device=device)
         self.flat_grads = torch.zeros(total, device=device)
@@ -233,10 +286,25 @@ class ResVAE(nn.Module):
         for n, m in self.named_modules():
             if isinstance(m, AdvNetScrubber):
                 frozen.update(id(x) for x in m.modules())
-        for m, pname, shape, off, numel in slots:
-            p = nn.Parameter(self.flat_params[off: off + numel].view(shape), requires_grad=id(m) not in frozen)
+        for m, pname, shape, off, numel, jn in slots:
+            if jn is None:
+                view, eoff = self.flat_params[off: off + numel].view(shape), 0
+            else:
+                jshape, axis, start, length = jn
+                view = self.flat_params[off: off + numel].view(jshape).narrow(axis, start, length)
+                eoff = start  # the slices run along the last (unit-stride) axis: element offset of the view in its region
+            p = nn.Parameter(view, requires_grad=id(m) not in frozen)
             m.register_parameter(pname, p)
-            self._slots.append((p, off, numel, shape))
+            self._slots.append((p, off, numel, shape, jn, eoff))
+        # the joint head tensors themselves (plain views of the flat buffers, not Parameters: the optimizer sees the slices)
+        wo, wn = regions["heads.w"]
+        bo, bn_ = regions["heads.b"]
+        jw = self.flat_params[wo: wo + wn].view(1, fm.in_lib, n_mu + n_sig)
+        jb = self.flat_params[bo: bo + bn_]
+        jw.grad = self.flat_grads[wo: wo + wn].view(1, fm.in_lib, n_mu + n_sig)
+        jb.grad = self.flat_grads[bo: bo + bn_]
+        self._fc_heads = _JointLinear(jw, jb, fm.in_lib, n_mu + n_sig, fm.in_f, fm.out_f + fs.out_f)
+        slots = [t[:5] for t in slots]
         # contiguous span of the decoder's parameters in the flat buffers (first all-reduce bucket)
         dec_ids = {id(m) for m in self.decoder.modules()}
         dec = [(off, off + (numel + 3) // 4 * 4) for m, pname, shape, off, numel in slots if id(m) in dec_ids]
@@ -256,9 +324,11 @@ class ResVAE(nn.Module):
         # contiguous [lo, hi) element ranges of the flat buffers that hold TRAINABLE parameters: the optimizer, like torch's,
         # only touches those (the AdvNetScrubber ensemble is frozen, disentangle.py:670-671 -- AdamW must not decay it)
         spans = []
+        seen = set()
         for m, pname, shape, off, numel in slots:
-            if id(m) in frozen:
+            if id(m) in frozen or off in seen:  # (the slices of a joint tensor share one region)
                 continue
+            seen.add(off)
             end = off + (numel + 3) // 4 * 4
             if spans and spans[-1][1] == off:
                 spans[-1][1] = end
@@ -272,11 +342,14 @@ class ResVAE(nn.Module):
         """Make every trainable parameter's .grad a view of the flat gradient buffer (the
         reference loop sets param.grad = None before backward, trainer.py:160-161)."""
         base = self.flat_grads.data_ptr()
-        for p, off, numel, shape in self._slots:
+        for p, off, numel, shape, jn, eoff in self._slots:
             if not p.requires_grad:
                 continue
-            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
-                p.grad = self.flat_grads[off: off + numel].view(shape)
+            if p.grad is None or p.grad.data_ptr() != base + 4 * (off + eoff):
+                if jn is None:
+                    p.grad = self.flat_grads[off: off + numel].view(shape)
+                else:  # column slice of a joint tensor's gradient
+                    p.grad = self.flat_grads[off: off + numel].view(jn[0]).narrow(jn[1], jn[2], jn[3])
 
     def _apply(self, fn, recurse=True):
         # parameters are views of flat_params: moving/casting them individually would break
@@ -326,16 +399,21 @@ class ResVAE(nn.Module):
                 self._split_users[key] = (c, p)
         return c
 
-    def _lin(self, name, p: LinearP, batch, ld_in=None, ld_out=None):
+    def _lin(self, name, p: LinearP, batch, ld_in=None, ld_out=None, pieces=None):
         key = (name, batch, ld_in, ld_out)
         c = self._convs.get(key)
         if c is None:
-            c = ops.Conv(batch, 1, p.in_lib, p.out_lib, 1, ld_in=ld_in, ld_out=ld_out)
+            c = ops.Conv(batch, 1, p.in_lib, p.out_lib, 1, ld_in=ld_in, ld_out=ld_out, pieces=pieces)
             c.flops = 2.0 * batch * p.in_f * p.out_f  # algorithmic: unpadded features
             self._convs[key] = c
             if c.pieces:
                 self._split_users[key] = (c, p)
         return c
+
+    def _heads_pieces(self):
+        """Arithmetic of the joint fc_mu || fc_sigma GEMM: with a diagonal factor it is skinny (2 z columns over a deep reduction) --
+        the fp32 split-K kernels whatever the batch; a full Cholesky factor (z (z + 3) / 2 columns) follows the model's precision."""
+        return 0 if self.is_diag else None
 
     def _new_pass(self):
         """Start of forward / encode / decode: the master weights may have changed since the last pass, so
@@ -707,9 +785,8 @@ class ResVAE(nn.Module):
         zp = pad16(self.z_dim)
         flat = a.view(B, L * pad16(ch[-1]))
         h = self._buf("enc.h", (B, self._hw), zero=True)
-        self._lin("fc_mu", enc.fc_mu, B, ld_out=self._hw).fwd(flat, enc.fc_mu.weight, enc.fc_mu.bias, h)
-        fs = enc.fc_sigma[0]
-        self._lin("fc_sigma", fs, B, ld_out=self._hw).fwd(flat, fs.weight, fs.bias, h[:, zp:])
+        hd = self._fc_heads  # fc_mu || fc_sigma[0]: one GEMM writes [mu | raw]
+        self._lin("fc_heads", hd, B, pieces=self._heads_pieces()).fwd(flat, hd.weight, hd.bias, h)
         return B, flat, h
 
     def _heads(self, B, h, eps):
@@ -905,17 +982,20 @@ class ResVAE(nn.Module):
                     outs = r.forward(latent(k), self.z_dim) if r.fused else r.forward(latent(k))
                     data_o["disentangle"][method][k] = [o[:, : m.ensemble.out_dim] for o in outs]
                 elif method == "adversarial_net":
-                    # the un-shuffled evaluation on (mu, var) that VAE.forward stores (residual.py:357-358); the loss recomputes
-                    # it with the shuffle
-                    r = self._runner(method + ".fwd", k, m.ensemble, B)
-                    if r.fused:
-                        outs = r.forward(latent(k), self.z_dim, src1=self._var32(data_o["var"]))
-                    else:
-                        x = self._buf(f"an.{k}.x0", (B, pad16(m.ensemble.in_dim)), zero=True)
-                        x[:, : self.z_dim] = latent(k)[:, : self.z_dim]
-                        x[:, self.z_dim: self.z_dim + self.conditional_dim] = data_o["var"]
-                        outs = r.forward(x)
-                    data_o["disentangle"][method][k] = [torch.softmax(o[:, :2], -1) for o in outs]
+                    # the un-shuffled evaluation on (mu, var) that VAE.forward stores (residual.py:357-358); the loss ignores it and
+                    # recomputes the ensemble with the shuffle.  On the training fast path (defer_tail: data_o aliases per-pass buffers
+                    # anyway) it is evaluated on first access, so a step that never reads it does not launch it
+                    def unshuffled(k=k, m=m, var=data_o["var"]):
+                        r = self._runner("adversarial_net.fwd", k, m.ensemble, B)
+                        if r.fused:
+                            outs = r.forward(latent(k), self.z_dim, src1=self._var32(var))
+                        else:
+                            x = self._buf(f"an.{k}.x0", (B, pad16(m.ensemble.in_dim)), zero=True)
+                            x[:, : self.z_dim] = latent(k)[:, : self.z_dim]
+                            x[:, self.z_dim: self.z_dim + self.conditional_dim] = var
+                            outs = r.forward(x)
+                        return [torch.softmax(o[:, :2], -1) for o in outs]
+                    data_o["disentangle"][method][k] = _LazyList(unshuffled) if (self.training and self.defer_tail) else unshuffled()
                 elif method == "moving_avg_lsq":
                     data_o["disentangle"][method][k] = m(latent(k)[:, : self.z_dim])
                 elif method in ("moving_avg", "qda"):  # stateful filters: forward() is a no-op (disentangle.py:31-32,127-128)
@@ -949,7 +1029,9 @@ class ResVAE(nn.Module):
     # ------------------------------------------------------------------ backward schedule
     def make_total(self, total):
         """Wrap the device scalar `total` so that ``total.backward()`` runs the HIP backward."""
-        anchor = self.flat_params.new_zeros((), requires_grad=True)
+        anchor = self.__dict__.get("_anchor")
+        if anchor is None:  # a leaf that makes the returned scalar require grad; the same one every step (no per-step fill launch)
+            anchor = self.__dict__["_anchor"] = self.flat_params.new_zeros((), requires_grad=True)
         return _TotalLoss.apply(anchor, total, self)
 
     def _scrub_backward(self, pend):
@@ -1095,14 +1177,11 @@ class ResVAE(nn.Module):
             ops.heads_tril_bwd(h, self._hw, st["eps"], self._L, g_zc, zcp, d_mu, zp, pend["kl_scale"], pend.get("dlv"), dh, B,
                                self.z_dim, zp)
         flat = st["flat"]
-        fm, fs = enc.fc_mu, enc.fc_sigma[0]
-        lm = self._lin("fc_mu", fm, B, ld_out=self._hw)
-        ls = self._lin("fc_sigma", fs, B, ld_out=self._hw)
-        self._wgrad(lm, flat, dh, fm, acc)
-        self._wgrad(ls, flat, dh[:, zp:], fs, acc)
+        hd = self._fc_heads  # fc_mu || fc_sigma[0] as one Linear: one weight-gradient and one data-gradient launch
+        lh = self._lin("fc_heads", hd, B, pieces=self._heads_pieces())
+        self._wgrad(lh, flat, dh, hd, acc)
         g_flat = self._buf("g.flat", tuple(flat.shape))
-        lm.dgrad(dh, fm.weight, g_flat)
-        ls.dgrad(dh[:, zp:], fs.weight, g_flat, accumulate=True)
+        lh.dgrad(dh, hd.weight, g_flat)
         # ---- encoder blocks
         elens = [W]
         for blk in enc.res_layers:

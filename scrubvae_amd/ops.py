@@ -727,8 +727,8 @@ def adam_advance(hyper, beta1, beta2):
     check(_lib.lib().svae_adam_advance(_p(hyper), beta1, beta2, _stream()), "adam_advance")
 
 
-def clip_grads(g, sumsq, max_norm):
-    check(_lib.lib().svae_clip_grads(_p(g), g.numel(), _p(sumsq), float(max_norm), _stream()), "clip_grads")
+def clip_grads(g, sumsq, max_norm, norm_out=None):
+    check(_lib.lib().svae_clip_grads(_p(g), g.numel(), _p(sumsq), float(max_norm), _p(norm_out), _stream()), "clip_grads")
 
 
 def small_solve(A, B, diag=None):
@@ -842,6 +842,19 @@ def sumsq_partial(x, part):
 
 def reduce_rows(part, rows, k, scale, out, accumulate=False):
     check(_lib.lib().svae_reduce_rows(_p(part), rows, k, float(scale), _p(out), int(accumulate), _stream()), "reduce_rows")
+
+
+def reduce_rows_scaled(part, rows, scales, out):
+    """out[c] = scales[c] * sum over rows of part[rows][len(scales)] (one launch; len(scales) <= 8)"""
+    k = len(scales)
+    check(_lib.lib().svae_reduce_rows_scaled(_p(part), rows, k, (C.c_float * k)(*[float(v) for v in scales]), _p(out), _stream()),
+          "reduce_rows_scaled")
+
+
+def loss_total(terms, weights, out):
+    """out[0] = sum_i weights[i] * terms[i] (the reference's running `total`, losses.py:320-322) in one launch"""
+    n = len(weights)
+    check(_lib.lib().svae_loss_total(_p(terms), (C.c_float * n)(*[float(v) for v in weights]), n, _p(out), _stream()), "loss_total")
 
 
 def relu_fwd(x, y):

@@ -29,8 +29,36 @@ _EARLY_SCRUB = os.environ.get("SVAE_EARLY_SCRUB", "1") != "0"  # (0 = the heads'
 SUPPORTED = ("rotation", "prior", "jpe", "root", "total_correlation")
 
 
-def _scalar(model, name):
-    return model._buf("loss." + name, (1,), zero=True)
+class _LossPack:
+    """The loss terms of one get_batch_loss call as slots of ONE device buffer: every term is reduced straight into its slot, the
+    running `total` of the reference (losses.py:320-322) is one `svae_loss_total` launch over the slots, and the dict handed back
+    holds 0-dim views of one snapshot of the buffer -- instead of an axpy and a clone per term."""
+
+    def __init__(self, model, loss_scale):
+        from .._lib import MAX_LOSS_TERMS
+        self.buf = model._buf("loss.pack", (MAX_LOSS_TERMS + 1,), zero=True)
+        self.loss_scale = loss_scale
+        self.keys, self.weights = [], []
+
+    def slot(self, key):
+        """1-element view for loss term `key` (None: an unnamed spare slot); its weight in the total is loss_scale[key] (0 if absent)"""
+        i = len(self.keys)
+        if i >= self.buf.numel() - 1:
+            raise RuntimeError("too many loss terms for one get_batch_loss call")
+        self.keys.append(key)
+        self.weights.append(float(self.loss_scale.get(key, 0.0)) if key is not None else 0.0)
+        return self.buf[i: i + 1]
+
+    def finish(self, batch_loss):
+        """total into the slot behind the last term, one snapshot, views into `batch_loss` (dict order = the order of slot() calls
+        that registered a placeholder); returns the 0-dim total"""
+        n = len(self.keys)
+        ops.loss_total(self.buf, self.weights, self.buf[n: n + 1])
+        snap = self.buf[: n + 1].clone()
+        for i, k in enumerate(self.keys):
+            if k is not None:
+                batch_loss[k] = snap[i]
+        return snap[n]
 
 
 def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm=None):
@@ -50,13 +78,14 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
             continue
         raise NotImplementedError(f"loss '{k}' is outside this build's scope (SURVEY 8a: L5/A2 rows)")
     batch_loss = {}
-    total = _scalar(model, "total")
-    total.zero_()
+    pack = _LossPack(model, loss_scale)
     dev_data = {k: v for k, v in data.items()}
 
-    def add_total(key, value):
-        if loss_scale[key] != 0:
-            ops.axpy(float(loss_scale[key]), value, total)
+    def term(key):
+        """device slot of loss term `key`, registered in batch_loss in call order (filled from the snapshot at the end); it enters
+        the total with weight loss_scale[key] when that key exists and is non-zero, as in the reference"""
+        batch_loss[key] = None
+        return pack.slot(key)
 
     # ---- rotation (L4): seeds an extra gradient on x6d_hat that the tail adds
     ext_dx6d = None
@@ -69,18 +98,12 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
         x6d_hat = model._buf("out.x6d", (B, W, J, 6))
         ext_dx6d = model._buf("rot.dx", (B * W, J * 6)) if train else None
         ops.rot_loss(x6d, x6d_hat, float(loss_scale["rotation"]), part, ext_dx6d, n)
-        v = _scalar(model, "rotation")
-        ops.reduce_rows(part, part.numel(), 1, 1.0, v)
-        batch_loss["rotation"] = v.view(()).clone()
-        add_total("rotation", v)
+        ops.reduce_rows(part, part.numel(), 1, 1.0, term("rotation"))
 
     # ---- prior (L3): KL partials were produced by the heads kernel in forward
     kl_scale = 0.0
     if "prior" in loss_scale:
-        v = _scalar(model, "prior")
-        ops.reduce_rows(st["klp"], st["klp"].numel(), 1, 1.0 / Bg, v)
-        batch_loss["prior"] = v.view(()).clone()
-        add_total("prior", v)
+        ops.reduce_rows(st["klp"], st["klp"].numel(), 1, 1.0 / Bg, term("prior"))
         kl_scale = float(loss_scale["prior"]) / Bg
 
     # ---- jpe (L1) + root (L2): fused tail, also produces d total / d conv_out
@@ -106,26 +129,16 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
         model._fork(_tail, k=1)
     else:
         _tail()
-    for k in ("jpe", "root"):  # placeholders: dict order as the serial schedule writes it
-        if k in loss_scale:
-            batch_loss[k] = None
+    # two adjacent slots (dict order as the serial schedule writes it); a term that is not configured keeps an unnamed spare slot
+    for k in ("jpe", "root"):
+        term(k) if k in loss_scale else pack.slot(None)
+    tail_slots = pack.buf[len(pack.keys) - 2: len(pack.keys)]
 
     def join_tail():
         model._join_side(1)
         lp = tail_out["r"][2]
-        nb = lp.shape[0]
-        if "jpe" in loss_scale:
-            v = _scalar(model, "jpe")
-            ops.reduce_rows(lp, nb, 2, 1.0 / (Bg * 3 * J), model._buf("tail.sums", (2,)))
-            v.copy_(model._buf("tail.sums", (2,))[0:1])
-            batch_loss["jpe"] = v.view(()).clone()
-            add_total("jpe", v)
-        if "root" in loss_scale:
-            v = _scalar(model, "root")
-            ops.reduce_rows(lp, nb, 2, 1.0 / Bg, model._buf("tail.sums2", (2,)))
-            v.copy_(model._buf("tail.sums2", (2,))[1:2])
-            batch_loss["root"] = v.view(()).clone()
-            add_total("root", v)
+        if "jpe" in loss_scale or "root" in loss_scale:  # the two column sums of the tail's partials, each with its own normalisation
+            ops.reduce_rows_scaled(lp, lp.shape[0], [1.0 / (Bg * 3 * J), 1.0 / Bg], tail_slots)
         return tail_out["r"][3]
 
     if not fork_tail:  # serial schedule: the terms enter the total in the reference's order
@@ -165,7 +178,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     # ---- mcmi (losses.py:221-225): KDE mutual information between mu and the conditioning variables under the
     # estimator built from the previous batch; zero (shaped like the jpe term, as in the reference) before the first refresh
     if "mcmi" in loss_scale:
-        v = _scalar(model, "mcmi")
+        v = term("mcmi")
         if model.mi_estimator is not None:
             sc = float(loss_scale["mcmi"])
             mu_t = st["mu"][:, :z].detach().clone().requires_grad_(bool(train and sc != 0))
@@ -176,8 +189,6 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 d_mu[:, :z] += sc * torch.autograd.grad(val, mu_t)[0]
         else:
             v.zero_()
-        batch_loss["mcmi"] = v.view(()).clone()
-        add_total("mcmi", v)
     methods = disentangle_config["method"] if disentangle_config is not None else {}
     for method, keys in methods.items():
         nk = len(keys)
@@ -192,7 +203,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 c = 4.0 * nk * Bg
                 weights = [c ** -4, c ** -3, c ** -2, c ** -1]  # normalisation inside the loop (losses.py:279-284)
                 lk = key + "_gr"
-                v = _scalar(model, lk)
+                v = term(lk)
                 nb_r = ops.rowloss_blocks(B)
                 if runner.fused:  # the four members' losses and seed gradients in one launch, one reduction
                     part = model._buf("gr.part4", (4 * nb_r,))
@@ -220,8 +231,6 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                             ops.mse_sum(o, out_p, tgt, tgt.shape[-1], B, out_dim, sc, part, dpred)
                         ops.reduce_rows(part, nb_r, 1, w, v, accumulate=True)
                         d_outs.append(dpred)
-                batch_loss[lk] = v.view(()).clone()
-                add_total(lk, v)
                 if train and loss_scale[lk] != 0:
                     scrub.append(dict(kind="gr", runner=runner, d_outs=d_outs, alpha=m.alpha,
                                       lin=None if lin is None else (lin["out"][key]["z_null"], lin["leaves"][key])))
@@ -244,7 +253,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 D = model.conditional_dim
                 runner = model._runner(method, key, m.ensemble, B, halves=2)
                 lk = key + "_an"
-                vv = _scalar(model, lk)
+                vv = term(lk)
                 nb_r = ops.rowloss_blocks(2 * B)
                 w = -1.0 / (4 * Bg)
                 if runner.fused:
@@ -272,8 +281,6 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                         ops.double_softmax_ce_sum(o, 16, 2 * B, float(loss_scale[lk]) * w, part, dl)
                         ops.reduce_rows(part, nb_r, 1, w, vv, accumulate=True)
                         d_outs.append(dl)
-                batch_loss[lk] = vv.view(()).clone()
-                add_total(lk, vv)
                 if train and loss_scale[lk] != 0:
                     scrub.append(dict(kind="an", runner=runner, d_outs=d_outs))
             elif method == "moving_avg_lsq":  # losses.py:237-246
@@ -281,11 +288,9 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 lk = key + "_mals"
                 y0, y1 = data_o["disentangle"][method][key]
                 tgt = model._prep(data[key])
-                v = _scalar(model, lk)
+                v = term(lk)
                 v.copy_((m.evaluate_loss(y0, y1, tgt) / Bg).reshape(1))
-                batch_loss[lk] = v.view(()).clone()
                 if lk in loss_scale:
-                    add_total(lk, v)
                     if train and loss_scale[lk] != 0:  # d/d mu of scale * (l0 + l1) / (2 Bg), decoders W constant
                         lat = st["mu"][:, : m.nx_in] if lin is None else lin["out"][key]["z_null"]
                         seed = m.latent_seed(y0, y1, tgt, lat.detach(), float(loss_scale[lk]) / Bg)
@@ -303,10 +308,8 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                     model._allreduce(zy)
                 Wd = ops.small_solve(zz, zy) if (zz.is_cuda and zz.shape[0] <= 64 and zy.shape[1] <= 64) else torch.linalg.solve(zz, zy)
                 res = zm @ Wd - tgt
-                v = _scalar(model, lk)
+                v = term(lk)
                 v.copy_((res * res).sum().reshape(1))
-                batch_loss[lk] = v.view(()).clone()
-                add_total(lk, v)
                 if train and sc != 0:
                     # d/d mu of the summed squared residual: the decoder is the minimiser, so its own dependence on mu
                     # contributes nothing (dL/dW = 0) and the gradient is 2 * res * W^T
@@ -321,11 +324,9 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                     val = m.evaluate_loss(mu_t, tgt)
                     if method == "qda":
                         val = val / Bg
-                v = _scalar(model, lk)
+                v = term(lk)
                 v.copy_(val.detach().reshape(1))
-                batch_loss[lk] = v.view(()).clone()
                 if lk in loss_scale:
-                    add_total(lk, v)
                     if train and sc != 0:  # seed of the HIP backward: d(scale * loss) / d mu through the small torch graph
                         push(leaves, torch.autograd.grad(val, leaves, retain_graph=lin is not None, allow_unused=True), sc)
             elif method == "linear":  # losses.py:258-265: the projection's own decoder regresses the feature
@@ -335,11 +336,9 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
                 tgt = model._prep(data[key])
                 with torch.set_grad_enabled(bool(train and sc != 0)):
                     val = ((pred - tgt) ** 2).sum() / nk / Bg
-                v = _scalar(model, lk)
+                v = term(lk)
                 v.copy_(val.detach().reshape(1))
-                batch_loss[lk] = v.view(()).clone()
                 if lk in loss_scale:
-                    add_total(lk, v)
                     if train and sc != 0:
                         leaves = lin["leaves"][key]
                         push(leaves, torch.autograd.grad(val, leaves, retain_graph=True, allow_unused=True), sc)
@@ -357,10 +356,7 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
         ops.tc_logvar(sig if model.is_diag else None, zp, None if model.is_diag else model._L, lv, B, z)
         lse_l, lse_a, lj = model._buf("tc.lse_l", (B, z)), model._buf("tc.lse_a", (B,)), model._buf("tc.loss", (B,))
         ops.tc_fwd(zc, zcp, mu_b, zp, lv, B, z, lse_l, lse_a, lj)
-        v = _scalar(model, "total_correlation")
-        ops.reduce_rows(lj, B, 1, 1.0 / B, v)
-        batch_loss["total_correlation"] = v.view(()).clone()
-        add_total("total_correlation", v)
+        ops.reduce_rows(lj, B, 1, 1.0 / B, term("total_correlation"))
         if train and loss_scale["total_correlation"] != 0:
             w = float(loss_scale["total_correlation"]) / (B * world)
             if model.is_diag:
@@ -381,10 +377,11 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
             model._scrub_backward(pend)
     if fork_tail:
         dy = join_tail()
+    total = pack.finish(batch_loss)  # one launch for the running total, one snapshot of all terms
     if train:
         pend["dy"] = dy
         model._pending = pend
-        batch_loss["total"] = model.make_total(total.view(()))
+        batch_loss["total"] = model.make_total(total)
     else:
-        batch_loss["total"] = total.view(()).clone()
+        batch_loss["total"] = total
     return batch_loss

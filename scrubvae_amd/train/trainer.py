@@ -126,15 +126,15 @@ def clip_grad_norm_(model, max_norm=1e6):
     buffer (trainer.py:164): gradients *= min(1, max_norm / (norm + 1e-6)), decided on the device
     (`svae_clip_grads` reads the squared norm and returns without touching the gradients when the
     clip does not bite, which is always with the reference's max_norm=1e6 unless a step diverges).
-    Returns the total norm as a device tensor.  Frozen parameters have no gradient (their span of
-    the flat buffer stays zero)."""
+    Returns the total norm as a 0-dim device tensor -- a view of a per-model buffer that the next call overwrites (clone it to
+    keep it across steps).  Frozen parameters have no gradient (their span of the flat buffer stays zero)."""
     n = model.flat_grads.numel()
     part = model._buf("gn.part", (ops.sumsq_blocks(n),))
-    out = model._buf("gn.out", (1,))
+    out = model._buf("gn.out", (2,))  # [sum of squares, norm]
     ops.sumsq_partial(model.flat_grads, part)
     ops.reduce_rows(part, part.numel(), 1, 1.0, out)
-    ops.clip_grads(model.flat_grads, out, max_norm)
-    return out.sqrt().view(())
+    ops.clip_grads(model.flat_grads, out, max_norm, out[1:])
+    return out[1]
 
 
 def get_optimizer_and_lr_scheduler(model, train_config, load_path=None, start_epoch=None):

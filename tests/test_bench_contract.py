@@ -136,3 +136,22 @@ def test_bench_plain_command_line_two_ranks():
     assert ex["grads"] > 0 and ex["bn"] == 0      # per-rank BatchNorm statistics: no BatchNorm collective
     assert "roofline" in d and "cpu_baseline" not in d
     assert c["streams"].startswith("one stream") == (c["side_streams"] == 0)
+
+
+def test_bench_products_per_template():
+    """roofline.peak divides the dense matrix-core peak by the products per multiply of the dominant TEMPLATE: every kernel family's
+    name must parse (the all-taps weight-gradient and 12-wave halo templates carry no piece count in their arguments)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    f = bench.template_products
+    assert f("gather_halo_bf16s_kernel<128, 128, 2, 4, 2, 160, false>", "f16x3b3") == 3
+    assert f("gather_halo_bf16s_kernel<256, 128, 3, 4, 2, 320, false>", "bf16x6") == 6
+    assert f("gather_gemm_bf16s_ws_kernel<128, 128, 2, 2, 2, 2, 0, false>", "f16x3b3") == 3
+    assert f("gather_halo_ws_bf16s_kernel<256, 128, 2, 4, 2, 264, 0, false, 3, false>", "f16x3b3") == 3
+    assert f("gather_halo_ws4_bf16s_kernel<256, 128, 264, 88, true, false, 0>", "f16x3b3") == 3
+    assert f("gather_halo_ws4m_bf16s_kernel<256, 128, 320, 64, true>", "f16x3b3") == 3
+    assert f("wgrad_taps16_bf16s_kernel<128, 128, 6, 1, false>", "f16x3b3") == 3
+    assert f("wgrad_taps_bf16s_kernel<64, 128, 5, 2, false>", "bf16x6b3") == 3
+    assert f("wgrad_gemm_bf16s_kernel<256, 256, 2, 1, 2, 4>", "f16x3b3") == 3
+    assert f("wgrad_gemm_bf16s_kernel<128, 128, 3, 2, 2, 2>", "bf16x6") == 6
+    assert f("gather_gemm_kernel<64, 64, false>", "f32") == 1

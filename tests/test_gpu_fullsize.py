@@ -2,7 +2,7 @@
 on exactly the kernel mix `bench.py` times, against the CPU oracle's `train_step` on the same seeded inputs.
 
   * configs[1]: B=1024, W=64, J=23, default channels, recon + KL, precisions `f16x3b3` (bench default) and `bf16x6b3`, the shipped `tuned_tiles.json`,
-    the library's default `SPLIT_MIN_FLOPS` (so the large layers run the split-bf16 halo / wave-specialised / 256-edge
+    the library's default `SPLIT_MIN_FLOPS` (so the large layers run the split-bf16 halo / 12-wave halo / all-taps
     weight-gradient templates and the small ones the fp32 kernels, as in the timed region);
   * configs[2]: B=4096, the full SC-VAE head set (conditional + 2 gradient-reversal ensembles + adversarial net), the
     shuffle permutation injected on both sides.
@@ -38,7 +38,7 @@ LR = 1e-4
 WIDE6 = (64, 128, 256, 512, 1024, 2048, 4096)  # BASELINE configs[4]: six residual blocks up to 4096 channels, window 256
 
 
-def _run(B, full, precision, seed, window=64, channel=None, expect=("gather_halo_bf16s_kernel", "wgrad_gemm_bf16s_kernel<256"),
+def _run(B, full, precision, seed, window=64, channel=None, expect=("gather_halo_bf16s_kernel", "gather_halo_ws4", "wgrad_taps"),
          out_tol=2e-5):
     from scrubvae_amd import ops
     from scrubvae_amd.train.losses import get_batch_loss

@@ -81,7 +81,14 @@ def test_step0_matches_reference_fixture(golden_dir, name):
             # (test_oracle_golden holds the oracle itself to 6e-2 there; the fp16-piece forward measured 8.7e-2 on one of them)
             assert dd < (1e-1 if (r.numel() == 1 and cfg.window > 64) else 5e-2), (k, dd)
         if k.startswith("s0/gradnorm/"):
-            assert abs(float(grads[k[12:]].norm()) - float(fx[k])) <= 2e-2 * (float(fx[k]) + 1e-3 * gmax), k
+            # Single PReLU slopes get 1e-1: the loss gradient is DISCONTINUOUS across a PReLU kink, and with B = 4 one element whose
+            # pre-activation lies within the forward tolerance of zero (|u| ~ 1e-6: ~0.1 expected per step over the ~1e5 activations of
+            # this model) can sit on the other side than in the reference's fp32 run.  Measured (tools/slope_noise.py on this fixture,
+            # f16x3b3): 1 of 12,544 elements of the last decoder stage flipped, which moved every upstream gradient tensor by <= 1 %
+            # in max-norm and the smallest slope gradient (|g| = 0.5 of a 25 gradient scale) by 6.8 %; with the same kernels and the
+            # BatchNorm statistics rounded differently (10 variants) all seventeen slopes sit 1e-5..5e-4 from the fp64 oracle.
+            tol = 1e-1 if grads[k[12:]].numel() == 1 else 2e-2
+            assert abs(float(grads[k[12:]].norm()) - float(fx[k])) <= tol * (float(fx[k]) + 1e-3 * gmax), k
     gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values()))
     assert rel(gn, fx["s0/grad_norm"]) < (1e-2 if "rotation" in loss_scale else 1e-3)
 
