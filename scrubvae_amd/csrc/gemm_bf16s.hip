@@ -3009,6 +3009,22 @@ static int launch_halo256(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, 
   return SVAE_OK;
 }
 
+// V = 19: the halo kernel on 256 x 160 tiles, 8 x 1 waves of 32 x 160 (code 19128128; the fields of the code are placeholders).  For
+// the output conv (141 -> 144 channels): ONE column tile instead of three 64-wide ones -- 10 % instead of 25 % of the matrix work on
+// padding columns, and the activation image of a channel block staged once instead of three times.  Two pieces (bf16 or fp16).
+static int launch_halo256_wide(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
+  if (pieces != 2 && pieces != SVAE_PIECES_F16X2) { set_error("split gather: the 256 x 160 halo tile is built for 2 pieces"); return SVAE_ERR_SHAPE; }
+  if (rows > 528) { set_error("split gather: 256-row halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
+  if (pieces == SVAE_PIECES_F16X2) {
+    if (rows <= 320) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 160, 2, 8, 1, 320, true>), grid, dim3(512), 0, st, sa);
+    else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 160, 2, 8, 1, 528, true>), grid, dim3(512), 0, st, sa);
+  } else {
+    if (rows <= 320) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 160, 2, 8, 1, 320>), grid, dim3(512), 0, st, sa);
+    else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 160, 2, 8, 1, 528>), grid, dim3(512), 0, st, sa);
+  }
+  return SVAE_OK;
+}
+
 // V = 10 / 11: the wave-specialised halo kernel (8 consumer + 2 producer waves) on 128- / 256-row tiles (row field of the code: 128).
 // Instantiated where two image buffers + two weight stages fit the 160 KiB of LDS.
 template <int BM, int BN>
@@ -3146,6 +3162,14 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
     return check_launch("gather_halo_ws_bf16s<dbg>");
   }
 #endif
+  if (v == 19) {  // 256 x 160 tiles
+    if (t.bm != 128 || t.bn != 128) { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_SHAPE; }
+    for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + 255) / 256);
+    const int nb = g.blocks_m[0] + g.blocks_m[1];
+    if (nb == 0) return SVAE_OK;
+    if (int e = launch_halo256_wide(sa, dim3(nb, (g.N + 159) / 160), st, pieces, halo_rows(g, 256))) return e;
+    return check_launch("gather_halo_bf16s<256,160>");
+  }
   if (v == 16 || v == 17 || v == 18) {
     if (t.bm != 128 || (t.bn != 128 && t.bn != 64)) { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_SHAPE; }
     for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + 255) / 256);
@@ -3300,7 +3324,7 @@ extern "C" int svae_conv_dgrad_stats_tiles(const svae_conv_desc* d, int* col_blo
   Tile t;
   if (!decode_tile(d->tile[1], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
   const int bm = (t.dma == 9 || t.dma == 11 || t.dma >= 13) ? 256 : t.bm;
-  if (col_blocks) *col_blocks = (g.N + t.bn - 1) / t.bn;
+  if (col_blocks) *col_blocks = t.dma == 19 ? (g.N + 159) / 160 : (g.N + t.bn - 1) / t.bn;
   return (int)((g.M[0] + bm - 1) / bm + (g.M[1] + bm - 1) / bm);
 }
 
@@ -3354,6 +3378,7 @@ extern "C" int svae_conv_split_tile(const svae_conv_desc* d, int kind, int* bm, 
   if (t.dma == 13) { *bm = 256; *rmax = 264; }
   if (t.dma == 14 || t.dma == 15) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 264 ? 264 : 320; }
   if (t.dma >= 16 && t.dma <= 18) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 264 ? 264 : 320; }
+  if (t.dma == 19) { const int r = halo_rows(g, 256); *bm = 256; *bn = 160; *rmax = r <= 320 ? 320 : 528; }
   return SVAE_OK;
 }
 

@@ -18,6 +18,11 @@ for a in list(sys.argv):
         table = {k: v for k, v in table.items() if not k.startswith(pre)}
         sys.argv.remove(a)
 CONFIG4 = "--config4" in sys.argv  # BASELINE configs[4]: window 256, six blocks 64..4096 (bench.py --window 256 --channels wide6)
+for a in list(sys.argv):  # --retune-match=fwd,:64:144:64:144: -- with --keep, drop the entries of that kind whose key contains the substring
+    if a.startswith("--retune-match="):
+        kind, sub = a.split("=", 1)[1].split(",", 1)
+        table = {k: v for k, v in table.items() if not (k.startswith(kind) and sub in k)}
+        sys.argv.remove(a)
 sys.argv = [a for a in sys.argv if a not in ("--keep", "--config4")]
 WIDE6 = [64, 128, 256, 512, 1024, 2048, 4096]
 DEFAULT = [64, 128, 256, 512, 1024]
