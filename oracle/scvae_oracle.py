@@ -66,6 +66,7 @@ class OracleConfig:
     bn_eps: float = 1e-4  # residual.py:88,112,146,173
     bn_momentum: float = 0.1
     activation: str = "prelu"  # model.activation: "tanh" puts nn.Tanh() wherever the default has nn.PReLU() (residual.py:89)
+    prior: str = "gaussian"    # model.prior: "beta" = Beta posterior, fc_alpha / fc_beta heads (residual.py:223-239,301-302,328-331,453-456)
 
     @property
     def in_channels(self):  # get/model.py:33-35
@@ -164,9 +165,13 @@ def init_state_dict(cfg: OracleConfig, seed=0, dtype=torch.float32, scale=1.0):
         bn(p + ".add.0", ch[i + 1])
         prelu(p + ".add.1")
     flat = find_latent_dim(cfg.window, k, len(ch) - 1) * ch[-1]
-    lin("encoder.fc_mu", cfg.z_dim, flat)
-    sig = cfg.z_dim if cfg.diag else cfg.z_dim * (cfg.z_dim + 1) // 2
-    lin("encoder.fc_sigma.0", sig, flat)
+    if cfg.prior == "beta":  # residual.py:223-225
+        lin("encoder.fc_alpha", cfg.z_dim, flat)
+        lin("encoder.fc_beta", cfg.z_dim, flat)
+    else:
+        lin("encoder.fc_mu", cfg.z_dim, flat)
+        sig = cfg.z_dim if cfg.diag else cfg.z_dim * (cfg.z_dim + 1) // 2
+        lin("encoder.fc_sigma.0", sig, flat)
     lin("decoder.fc_in", flat, cfg.z_dim + cfg.conditional_dim)
     for j, i in enumerate(range(1, len(ch))):
         cin, cout = ch[-i], ch[-i - 1]
@@ -295,9 +300,35 @@ def encode(sd, cfg, data, train, new_stats=None):
     for i in range(len(cfg.channel) - 1):
         x = res_block(x, sd, f"encoder.res_layers.{i}", cfg, train, new_stats)
     flat = x.flatten(1)
+    if cfg.prior == "beta":
+        # ResidualEncoder.forward :235-239 (softplus + 1: one mode) and ResVAE.encode :453-456 (mu = the mode, rescaled to (-1, 1))
+        alpha = F.softplus(F.linear(flat, sd["encoder.fc_alpha.weight"], sd["encoder.fc_alpha.bias"])) + 1
+        beta = F.softplus(F.linear(flat, sd["encoder.fc_beta.weight"], sd["encoder.fc_beta.bias"])) + 1
+        mu = (alpha - 1 + 1e-8) / (alpha + beta - 2 + 2e-8) * 2 - 1
+        return {"alpha": alpha, "beta": beta, "mu": mu}
     mu = F.linear(flat, sd["encoder.fc_mu.weight"], sd["encoder.fc_mu.bias"])
     raw = F.linear(flat, sd["encoder.fc_sigma.0.weight"], sd["encoder.fc_sigma.0.bias"])
     return {"mu": mu, "L": cholesky_L(raw, cfg.z_dim, cfg.diag)}
+
+
+class _BetaRSample(torch.autograd.Function):
+    """Beta(alpha, beta).rsample() with the draw INJECTED (x in (0, 1), e.g. from torch's sampler): torch.distributions.Beta
+    draws through Dirichlet([alpha, beta]) and differentiates the draw implicitly (torch/distributions/dirichlet.py
+    _Dirichlet_backward: grad = _dirichlet_grad(x, conc, total) * (g - sum(x g))); with g on component 0 only:
+    d alpha = D(x, alpha, total) (1 - x) g,  d beta = -D(1 - x, beta, total) x g."""
+
+    @staticmethod
+    def forward(ctx, alpha, beta, x):
+        ctx.save_for_backward(alpha, beta, x)
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, beta, x = ctx.saved_tensors
+        conc = torch.stack([alpha, beta], -1)
+        xs = torch.stack([x, 1 - x], -1)
+        d = torch._dirichlet_grad(xs, conc, conc.sum(-1, True).expand_as(conc))
+        return d[..., 0] * (1 - x) * g, -d[..., 1] * x * g, None
 
 
 def conditional_var(cfg, data):
@@ -373,7 +404,10 @@ def forward(sd, cfg, data, train, eps=None, new_stats=None):
     """VAE.forward, residual.py:318-362.  eps [B,z] is the injected reparameterisation
     noise (reference draws randn_like(mu), :315)."""
     out = encode(sd, cfg, data, train, new_stats)
-    if train:
+    if cfg.prior == "beta":
+        # residual.py:328-331: z = Beta(alpha, beta).rsample() * 2 - 1, in train AND eval mode; eps = the injected draw in (0, 1)
+        z = _BetaRSample.apply(out["alpha"], out["beta"], eps.to(out["alpha"].dtype)) * 2 - 1
+    elif train:
         # sampling, residual.py:305-316: (L @ eps[...,None]).squeeze() + mu
         z = torch.matmul(out["L"], eps[..., None]).squeeze().add(out["mu"])
     else:
@@ -487,7 +521,12 @@ def batch_loss(sd, cfg, data, out, loss_scale, adv_perm=None):
     if "rotation" in loss_scale:
         bl["rotation"] = stable_rotation_loss(data["x6d"], out["x6d"])
     if "prior" in loss_scale:
-        bl["prior"] = prior_loss(out["mu"], out["L"])
+        if "L" in out:
+            bl["prior"] = prior_loss(out["mu"], out["L"])
+        else:  # losses.py:198-206: KL(Beta(alpha, beta) || Beta(1, 1)) summed, / batch
+            q = torch.distributions.Beta(out["alpha"], out["beta"])
+            p = torch.distributions.Beta(torch.ones_like(out["alpha"]), torch.ones_like(out["beta"]))
+            bl["prior"] = torch.distributions.kl_divergence(q, p).sum(-1).sum() / B
     if "jpe" in loss_scale:
         bl["jpe"] = mpjpe_loss(data["target_pose"], out["x6d"], cfg.kinematic_tree, data["offsets"])
     if "root" in loss_scale:

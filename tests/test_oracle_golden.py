@@ -52,6 +52,12 @@ SCENARIOS = {
                        {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_lin": 0.6, "heading_lin": 1.5,
                         "avg_speed_3d_gr": 1.0, "heading_gr": 2.0}, "adamw"),
     "tanh_tiny": (O.OracleConfig(diag=True, activation="tanh", **TINY), {"jpe": 1.0, "root": 1.0, "prior": 0.5}, "adamw"),
+    # model.prior = "beta" (make_fixtures.py --beta-only: the Beta draw injected through torch._sample_dirichlet, the implicit
+    # reparameterisation gradient is torch's own _dirichlet_grad on both sides)
+    "beta_tiny": (O.OracleConfig(diag=True, prior="beta", **TINY), {"jpe": 1.0, "root": 1.0, "prior": 0.5}, "adamw"),
+    "beta_full_tiny": (O.OracleConfig(diag=True, prior="beta", method=FULL_METHODS, features=["avg_speed_3d", "heading"],
+                                      discrete_classes={"ids": torch.arange(4)}, **TINY),
+                       {"jpe": 1.0, "root": 1.0, "prior": 0.5, "avg_speed_3d_gr": 1.0, "heading_gr": 2.0, "heading_an": 0.5}, "adamw"),
     # BASELINE config 5's shape: window 256; four blocks = the unmodified reference, six blocks = the
     # reference with only its default dilation list lengthened (it cannot build >4 blocks otherwise,
     # see make_fixtures.py)
@@ -76,6 +82,11 @@ def load_fixture(golden_dir, name):
     return fx, cfg, loss_scale, opt, sd, data
 
 
+def out_keys(cfg):
+    """data_o entries every fixture stores for step 0 (VAE.dist_params, residual.py:299-302)"""
+    return ("mu", "alpha", "beta", "z", "x6d", "root") if cfg.prior == "beta" else ("mu", "L", "z", "x6d", "root")
+
+
 def rel(a, b):
     a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
@@ -88,7 +99,7 @@ def test_oracle_step0_matches_reference(golden_dir, name):
     bl, grads, new_sd, out = O.train_step(
         sd, cfg, data, loss_scale, eps, adv_perm={k: perm for k in cfg.method.get("adversarial_net", [])},
         lr=1e-4, optimizer=opt)
-    for k in ("mu", "L", "z", "x6d", "root"):
+    for k in out_keys(cfg):
         assert rel(out[k].detach(), fx["s0/out/" + k]) < 2e-5, k
     for k in fx.files:
         if k.startswith("s0/loss/"):
@@ -113,7 +124,7 @@ def test_oracle_step0_matches_reference(golden_dir, name):
     assert rel(gn, fx["s0/grad_norm"]) < (1e-2 if "rotation" in loss_scale else 1e-3)
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "linear_gr_tiny", "full_j23_tiny"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "linear_gr_tiny", "full_j23_tiny", "beta_tiny"])
 def test_oracle_multistep_and_eval(golden_dir, name):
     """3 optimizer steps then an eval-mode forward.  Adam amplifies fp32 noise (sign-like
     first step), the reference run at 1 vs 8 threads diverges ~1e-5/step: gate 2e-3."""
@@ -130,7 +141,7 @@ def test_oracle_multistep_and_eval(golden_dir, name):
     for k in fx.files:
         if k.startswith("final_sd/") and "running" in k:
             assert rel(sd[k[9:]], fx[k]) < 5e-3, k
-    out = O.forward(sd, cfg, data, False)
+    out = O.forward(sd, cfg, data, False, eps=torch.from_numpy(fx["eps/0"]) if cfg.prior == "beta" else None)  # (beta draws in eval mode too)
     bl = O.batch_loss(sd, cfg, data, out, loss_scale,
                       {k: torch.from_numpy(fx["perm/0"]) for k in cfg.method.get("adversarial_net", [])})
     for k in ("mu", "x6d", "root"):
