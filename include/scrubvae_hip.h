@@ -255,6 +255,18 @@ int svae_heads_tril_bwd(const float* h, int ld, const float* eps, const float* L
                         const float* dmu, int ldm, float kl_scale, const float* dlv, float* dh, int batch,
                         int zdim, int raw_off, void* stream);
 
+/* model.prior = "beta" (residual.py:223-239,301-302,328-331,453-456; losses.py:198-206).  h [B, ld]: raw alpha at columns [0, z), raw beta
+ * at [raw_off, raw_off + z).  Forward: alpha = softplus(raw) + 1, beta likewise, mu = (alpha - 1 + 1e-8) / (alpha + beta - 2 + 2e-8) * 2 - 1
+ * (all [B, ldm]); kl_part[svae_heads_blocks] = partials of sum KL(Beta(alpha, beta) || Beta(1, 1)) (before the / B).  The draw
+ * x ~ Beta(alpha, beta) is the CALLER's (z = 2 x - 1; torch's sampler as RNG plumbing, injected in parity tests).  Backward:
+ * dh = [d raw_alpha | d raw_beta] from dz [B, lddz] (gradient wrt z, through the implicit reparameterisation of x: the reference's
+ * Beta.rsample = Dirichlet rsample with torch._dirichlet_grad, restated in the kernel), dmu [B, ldm] (seed on mu; may be NULL) and
+ * kl_scale * d KL. */
+int svae_heads_beta_fwd(const float* h, int ld, float* alpha, float* beta, float* mu, int ldm, float* kl_part, int batch, int zdim,
+                        int raw_off, void* stream);
+int svae_heads_beta_bwd(const float* h, int ld, const float* x, const float* alpha, const float* beta, int ldm, const float* dz,
+                        int lddz, const float* dmu, float kl_scale, float* dh, int batch, int zdim, int raw_off, void* stream);
+
 /* L5: total_correlation (losses.py:41-101), beta-TCVAE minibatch estimator, z detached.
  * svae_tc_logvar: lv[b,l] = log diag(L L^T) from sigma (diag; 2 log sigma) or a dense L.
  * svae_tc_fwd: loss[j] (TC = mean_j), plus the two log-sum-exp tables the backward reuses

@@ -139,6 +139,8 @@ SIGNATURES = {
     "svae_rot_loss": (I, [P, P, F, P, P, LL, P]),
     "svae_inv_kin": (I, [P, C.POINTER(F), C.POINTER(Tree), I, I, I, I, P, P, P, P, LL, P]),
     "svae_speed_parts": (I, [P, C.POINTER(I), C.POINTER(I), I, I, I, P, LL, P]),
+    "svae_heads_beta_fwd": (I, [P, I, P, P, P, I, P, I, I, I, P]),
+    "svae_heads_beta_bwd": (I, [P, I, P, P, P, I, P, I, P, F, P, I, I, I, P]),
     "svae_rot_blocks": (I, [LL]),
     "svae_adam_step": (I, [P, P, P, P, LL, F, F, F, F, F, I, I, F, P]),
     "svae_adam_step_dev": (I, [P, P, P, P, LL, P, F, F, F, F, I, F, P]),

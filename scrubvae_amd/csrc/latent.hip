@@ -221,6 +221,169 @@ __global__ __launch_bounds__(256) void tc_bwd_kernel(const float* __restrict__ z
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ Beta posterior (model.prior = "beta")
+// Reference: ResidualEncoder.forward residual.py:235-239 (alpha = softplus(fc_alpha) + 1, beta likewise), ResVAE.encode :453-456
+// (mu = the mode rescaled to (-1, 1)), VAE.forward :328-331 (z = Beta(alpha, beta).rsample() * 2 - 1), losses.py:198-206
+// (KL(Beta(alpha, beta) || Beta(1, 1)).sum() / B).  The arithmetic behind `rsample` and `kl_divergence` lives in the reference's
+// dependency PyTorch (environment.yml: pytorch=1.13.1; same algorithm in 2.10): the draw goes through Dirichlet([alpha, beta]) and
+// is differentiated IMPLICITLY -- torch/distributions/dirichlet.py: grad = dirichlet_grad(x, conc, total) * (g - sum(x g)) -- with
+// the scaled reparameterised gradient  D(x; a, total) = -(d/da cdf(x; a, total - a)) / pdf(x) / (1 - x)  evaluated by the published
+// piecewise approximation of ATen/native/Distributions.h (dirichlet_grad_one): a Taylor series for x near 0, the mirrored one for x
+// near 1, a Rice saddle-point expansion when both shapes exceed 6, else a fitted rational correction (its 72 coefficients are part of
+// the algorithm) to the analytic approximation x (psi(total) - psi(a)) / b.  Restated here in fp64 per element -- [B, z] elements, nothing
+// next to the trunk -- so that gradients agree with the CPU reference's fp64-accumulator evaluation.  The draw x itself comes from the
+// caller (torch's sampler as RNG plumbing, like eps of the Gaussian heads; injected in parity tests).
+__device__ inline double digamma_d(double x) {  // Cephes-style: recurrence up to x >= 10, then the asymptotic series
+  double r = 0.0;
+  while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+  const double z = 1.0 / (x * x);
+  const double y = z * (8.33333333333333333333e-2 + z * (-8.33333333333333333333e-3 + z * (3.96825396825396825397e-3 +
+                   z * (-4.16666666666666666667e-3 + z * (7.57575757575757575758e-3 + z * (-2.10927960927960927961e-2 +
+                   z * 8.33333333333333333333e-2))))));
+  return r + log(x) - 0.5 / x - y;
+}
+__device__ inline double trigamma_d(double x) {
+  double r = 0.0;
+  while (x < 10.0) { r += 1.0 / (x * x); x += 1.0; }
+  const double z = 1.0 / (x * x);
+  return r + 1.0 / x + 0.5 * z + (1.0 / x) * z * (1.0 / 6.0 + z * (-1.0 / 30.0 + z * (1.0 / 42.0 + z * (-1.0 / 30.0 + z * (5.0 / 66.0)))));
+}
+__device__ inline double beta_grad_alpha_small(double x, double a, double b) {  // x near 0: Taylor series in x
+  const double factor = digamma_d(a) - digamma_d(a + b) - log(x);
+  double numer = 1.0, series = numer / a * (factor + 1.0 / a);
+  for (int i = 1; i <= 10; ++i) {
+    numer *= ((double)i - b) * x / (double)i;
+    const double denom = a + (double)i;
+    series += numer / denom * (factor + 1.0 / denom);
+  }
+  const double r = x * pow(1.0 - x, -b) * series;
+  return r != r ? 0.0 : r;
+}
+__device__ inline double beta_grad_beta_small(double x, double a, double b) {
+  const double factor = digamma_d(a + b) - digamma_d(b);
+  double numer = 1.0, betas = 1.0, dbetas = 0.0, series = factor / a;
+  for (int i = 1; i <= 8; ++i) {
+    numer *= -x / (double)i;
+    dbetas = dbetas * (b - (double)i) + betas;
+    betas = betas * (b - (double)i);
+    series += numer / (a + (double)i) * (dbetas + factor * betas);
+  }
+  const double r = -pow(1.0 - x, 1.0 - b) * series;
+  return r != r ? 0.0 : r;
+}
+__device__ inline double beta_grad_alpha_mid(double x, double a, double b) {  // both shapes large: Rice saddle-point expansion
+  const double total = a + b, mean = a / total, sd = sqrt(a * b / (total + 1.0)) / total;
+  if (mean - 0.1 * sd <= x && x <= mean + 0.1 * sd) {  // the singularity at x = mean
+    const double poly = 47.0 * x * (b * b) * (b * b) + a * ((43.0 + 20.0 * (16.0 + 27.0 * b) * x) * (b * b) * b + a * (
+                        3.0 * (59.0 + 180.0 * b - 90.0 * x) * (b * b) + a * ((453.0 + 1620.0 * b * (1.0 - x) - 455.0 * x) * b + a * (
+                        8.0 * (1.0 - x) * (135.0 * b - 11.0)))));
+    const double pn = (1.0 + 12.0 * a) * (1.0 + 12.0 * b) / (total * total);
+    const double pd = 12960.0 * a * a * a * b * b * (1.0 + 12.0 * total);
+    return pn / (1.0 - x) * poly / pd;
+  }
+  const double prefactor = -x / sqrt(2.0 * a * b / total);
+  const double stirling = (1.0 + 1.0 / (12.0 * a) + 1.0 / (288.0 * a * a)) * (1.0 + 1.0 / (12.0 * b) + 1.0 / (288.0 * b * b)) /
+                          (1.0 + 1.0 / (12.0 * total) + 1.0 / (288.0 * total * total));
+  const double t1n = 2.0 * (a * a) * (x - 1.0) + a * b * (x - 1.0) - x * (b * b);
+  const double axbx = a * (x - 1.0) + b * x;
+  const double t1 = t1n / (sqrt(2.0 * a / b) * pow(total, 1.5) * axbx * axbx);
+  const double t2 = 0.5 * log(a / (total * x));
+  const double t3 = sqrt(8.0 * a * b / total) / (b * x + a * (x - 1.0));
+  const double t4 = pow(b * log(b / (total * (1.0 - x))) + a * log(a / (total * x)), -1.5);
+  return stirling * prefactor * (t1 + t2 * (t3 + (x < mean ? t4 : -t4)));
+}
+__device__ const double kDirichletC[2][3][3][4] = {  // fitted coefficients of ATen's rational correction (part of the published algorithm)
+    {{{1.003668233, -0.01061107488, -0.0657888334, 0.01201642863},
+      {0.6336835991, -0.3557432599, 0.05486251648, -0.001465281033},
+      {-0.03276231906, 0.004474107445, 0.002429354597, -0.0001557569013}},
+     {{0.221950385, -0.3187676331, 0.01799915743, 0.01074823814},
+      {-0.2951249643, 0.06219954479, 0.01535556598, 0.001550077057},
+      {0.02155310298, 0.004170831599, 0.001292462449, 6.976601077e-05}},
+     {{-0.05980841433, 0.008441916499, 0.01085618172, 0.002319392565},
+      {0.02911413504, 0.01400243777, -0.002721828457, 0.000751041181},
+      {0.005900514878, -0.001936558688, -9.495446725e-06, 5.385558597e-05}}},
+    {{{1, -0.02924021934, -0.04438342661, 0.007285809825},
+      {0.6357567472, -0.3473456711, 0.05454656494, -0.002407477521},
+      {-0.03301322327, 0.004845219414, 0.00231480583, -0.0002307248149}},
+     {{0.5925320577, -0.1757678135, 0.01505928619, 0.000564515273},
+      {0.1014815858, -0.06589186703, 0.01272886114, -0.0007316646956},
+      {-0.007258481865, 0.001096195486, 0.0003934994223, -4.12701925e-05}},
+     {{0.06469649321, -0.0236701437, 0.002902096474, -5.896963079e-05},
+      {0.001925008108, -0.002869809258, 0.0008000589141, -6.063713228e-05},
+      {-0.0003477407336, 6.959756487e-05, 1.097287507e-05, -1.650964693e-06}}}};
+__device__ inline double dirichlet_grad_d(float xf, float af, float totalf) {
+  // the branch decisions are taken in the input precision (float), the evaluation in double -- as the CPU kernel does for float tensors
+  const float bf = totalf - af, boundary = totalf * xf * (1.f - xf);
+  const double x = xf, a = af, total = totalf, b = total - a;
+  if (xf <= 0.5f && boundary < 2.5f) return (double)(float)beta_grad_alpha_small((float)x, (float)a, (float)bf);
+  if (xf >= 0.5f && boundary < 0.75f) return -(double)(float)beta_grad_beta_small((double)(1.f - xf), (double)bf, (double)af);
+  if (af > 6.f && bf > 6.f) return beta_grad_alpha_mid(x, a, b);
+  const double u = log(x), la = log(a) - u, lb = log(total) - la;
+  const double pu[3] = {1.0, u, u * u}, pa[3] = {1.0, la, la * la};
+  double p = 0.0, q = 0.0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double ua = pu[i] * pa[j];
+      p += ua * (kDirichletC[0][i][j][0] + lb * (kDirichletC[0][i][j][1] + lb * (kDirichletC[0][i][j][2] + lb * kDirichletC[0][i][j][3])));
+      q += ua * (kDirichletC[1][i][j][0] + lb * (kDirichletC[1][i][j][1] + lb * (kDirichletC[1][i][j][2] + lb * kDirichletC[1][i][j][3])));
+    }
+  return p / q * (x * (digamma_d(total) - digamma_d(a)) / b);
+}
+
+// alpha / beta / mu [B, ldm], kl_part[blocks] = partial of sum KL(Beta(alpha, beta) || Beta(1, 1)) (before the / B)
+__global__ __launch_bounds__(256) void heads_beta_fwd_kernel(const float* __restrict__ h, int ld, float* __restrict__ alpha,
+                                                              float* __restrict__ beta, float* __restrict__ mu, int ldm,
+                                                              float* __restrict__ kl_part, int batch, int zd, int raw_off) {
+  __shared__ float red4[4];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  float kl = 0.f;
+  if (i < (long long)batch * zd) {
+    const int b = (int)(i / zd), k = (int)(i - (long long)b * zd);
+    const float a = softplus_l(h[(long long)b * ld + k]) + 1.f, bt = softplus_l(h[(long long)b * ld + raw_off + k]) + 1.f;
+    alpha[(long long)b * ldm + k] = a;
+    beta[(long long)b * ldm + k] = bt;
+    mu[(long long)b * ldm + k] = (a - 1.f + 1e-8f) / (a + bt - 2.f + 2e-8f) * 2.f - 1.f;
+    const double ad = a, bd = bt, sd = (double)a + (double)bt;
+    kl = (float)(lgamma(sd) - lgamma(ad) - lgamma(bd) + (ad - 1.0) * digamma_d(ad) + (bd - 1.0) * digamma_d(bd) + (2.0 - sd) * digamma_d(sd));
+  }
+  const float t = block_sum_256(kl, red4);
+  if (threadIdx.x == 0) kl_part[blockIdx.x] = t;
+}
+
+// dh = [d raw_alpha | d raw_beta] from: dz (gradient wrt z = 2 x - 1 through the implicit reparameterisation of the draw x), dmu (seed on
+// the rescaled mode: the scrubbing heads read mu), kl_scale * d KL
+__global__ __launch_bounds__(256) void heads_beta_bwd_kernel(const float* __restrict__ h, int ld, const float* __restrict__ x,
+                                                              const float* __restrict__ alpha, const float* __restrict__ beta, int ldm,
+                                                              const float* __restrict__ dz, int lddz, const float* __restrict__ dmu,
+                                                              float kl_scale, float* __restrict__ dh, int batch, int zd, int raw_off) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)batch * zd) return;
+  const int b = (int)(i / zd), k = (int)(i - (long long)b * zd);
+  const float a = alpha[(long long)b * ldm + k], bt = beta[(long long)b * ldm + k];
+  const float total = a + bt;
+  double ga = 0.0, gb = 0.0;
+  if (dz) {
+    const float xv = x[i];
+    const double g = 2.0 * (double)dz[(long long)b * lddz + k];
+    ga += dirichlet_grad_d(xv, a, total) * (1.0 - (double)xv) * g;
+    gb -= dirichlet_grad_d(1.f - xv, bt, total) * (double)xv * g;
+  }
+  if (kl_scale != 0.f) {
+    const double tg = (2.0 - (double)total) * trigamma_d((double)total);
+    ga += (double)kl_scale * (((double)a - 1.0) * trigamma_d((double)a) + tg);
+    gb += (double)kl_scale * (((double)bt - 1.0) * trigamma_d((double)bt) + tg);
+  }
+  if (dmu) {
+    const double gm = dmu[(long long)b * ldm + k], S = (double)a + (double)bt - 2.0 + 2e-8, N = (double)a - 1.0 + 1e-8;
+    ga += gm * 2.0 * (S - N) / (S * S);
+    gb -= gm * 2.0 * N / (S * S);
+  }
+  const float ra = h[(long long)b * ld + k], rb = h[(long long)b * ld + raw_off + k];
+  dh[(long long)b * ld + k] = (float)(ga / (1.0 + exp(-(double)ra)));
+  dh[(long long)b * ld + raw_off + k] = (float)(gb / (1.0 + exp(-(double)rb)));
+}
+
 }  // namespace svae
 
 using namespace svae;
@@ -242,6 +405,26 @@ extern "C" int svae_heads_tril_bwd(const float* h, int ld, const float* eps, con
   hipLaunchKernelGGL(heads_tril_bwd_kernel, dim3(svae_heads_blocks(batch, zdim)), dim3(256), 0, (hipStream_t)stream, h, ld, eps, L,
                      dz, lddz, dmu, ldm, kl_scale, dlv, dh, batch, zdim, raw_off);
   return check_launch("heads_tril_bwd");
+}
+
+
+extern "C" int svae_heads_beta_fwd(const float* h, int ld, float* alpha, float* beta, float* mu, int ldm, float* kl_part, int batch,
+                                   int zdim, int raw_off, void* stream) {
+  SVAE_REQUIRE(h && alpha && beta && mu && kl_part && batch > 0 && zdim > 0 && raw_off >= zdim && ld >= raw_off + zdim && ldm >= zdim,
+               SVAE_ERR_ARG, "heads_beta_fwd: bad args");
+  const int blocks = (int)(((long long)batch * zdim + 255) / 256);
+  hipLaunchKernelGGL(heads_beta_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, ld, alpha, beta, mu, ldm, kl_part, batch,
+                     zdim, raw_off);
+  return check_launch("heads_beta_fwd");
+}
+
+extern "C" int svae_heads_beta_bwd(const float* h, int ld, const float* x, const float* alpha, const float* beta, int ldm, const float* dz,
+                                   int lddz, const float* dmu, float kl_scale, float* dh, int batch, int zdim, int raw_off, void* stream) {
+  SVAE_REQUIRE(h && alpha && beta && dh && batch > 0 && zdim > 0 && (!dz || x), SVAE_ERR_ARG, "heads_beta_bwd: bad args");
+  const int blocks = (int)(((long long)batch * zdim + 255) / 256);
+  hipLaunchKernelGGL(heads_beta_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, ld, x, alpha, beta, ldm, dz, lddz, dmu,
+                     kl_scale, dh, batch, zdim, raw_off);
+  return check_launch("heads_beta_bwd");
 }
 
 extern "C" int svae_tc_logvar(const float* sigma, int lds, const float* L, float* lv, int batch, int zdim, void* stream) {

@@ -101,8 +101,8 @@ class ResidualEncoder(nn.Module):
     def __init__(self, in_channels, ch, kernel, z_dim, window, activation="prelu", is_diag=False, prior="gaussian",
                  init_dilation=None):
         super().__init__()
-        if prior != "gaussian":
-            raise NotImplementedError("prior='beta' is not on the BASELINE path")
+        if prior not in ("gaussian", "beta"):
+            raise ValueError(f"prior {prior!r} not in ('gaussian', 'beta')")
         if init_dilation is not None:
             raise NotImplementedError("init_dilation is not supported by the HIP trunk yet")
         self.conv_in = ConvP(in_channels, ch[0], 7, 1, 3)
@@ -112,8 +112,12 @@ class ResidualEncoder(nn.Module):
         flatten_dim = self.latent_len * ch[-1]
         sig_dim = z_dim if is_diag else z_dim * (z_dim + 1) // 2
         idx = _flat_index(ch[-1], self.latent_len)
-        self.fc_mu = LinearP(flatten_dim, z_dim, in_index=idx)
-        self.fc_sigma = nn.Sequential(LinearP(flatten_dim, sig_dim, in_index=idx), Marker("CholeskyL"))
+        if prior == "beta":  # residual.py:223-225: Beta posterior, alpha = softplus(fc_alpha) + 1, beta likewise
+            self.fc_alpha = LinearP(flatten_dim, z_dim, in_index=idx)
+            self.fc_beta = LinearP(flatten_dim, z_dim, in_index=idx)
+        else:
+            self.fc_mu = LinearP(flatten_dim, z_dim, in_index=idx)
+            self.fc_sigma = nn.Sequential(LinearP(flatten_dim, sig_dim, in_index=idx), Marker("CholeskyL"))
 
 
 class ResidualDecoder(nn.Module):
@@ -187,7 +191,7 @@ class ResVAE(nn.Module):
                  prior="gaussian", device="cuda"):
         super().__init__()
         self.prior = prior
-        self.dist_params = ["mu", "L"]
+        self.dist_params = ["alpha", "beta"] if prior == "beta" else ["mu", "L"]  # residual.py:299-302
         self.in_channels, self.ch, self.window = in_channels, list(ch), window
         self.kernel, self.z_dim = kernel, z_dim
         self.is_diag = is_diag
@@ -198,7 +202,7 @@ class ResVAE(nn.Module):
         self.conditional_keys = conditional_keys
         self.discrete_classes = discrete_classes
         self.n_keypts = (in_channels - (3 if arena_size is not None else 0)) // 6
-        self.sig_dim = z_dim if is_diag else z_dim * (z_dim + 1) // 2
+        self.sig_dim = z_dim if (is_diag or prior == "beta") else z_dim * (z_dim + 1) // 2  # beta: the second head is fc_beta [z]
         self._hw = pad16(z_dim) + pad16(self.sig_dim)  # row width of the [mu | raw] head buffer
         self.encoder = ResidualEncoder(in_channels, ch, kernel, z_dim, window, activation, is_diag, prior, init_dilation)
         self.decoder = ResidualDecoder(in_channels, ch, kernel, z_dim, window, activation, conditional_dim, init_dilation)
@@ -251,7 +255,8 @@ class ResVAE(nn.Module):
         # side by side in ONE [1][in][z_p + sig_p] tensor (biases likewise) and each module's parameter is a column slice of it:
         # the two Linear layers are one GEMM forward, one data-gradient and one weight-gradient launch (module tree, parameter
         # names, shapes and state_dict unchanged; the slices are ordinary -- non-contiguous -- Parameters).
-        fm, fs = self.encoder.fc_mu, self.encoder.fc_sigma[0]
+        fm, fs = ((self.encoder.fc_alpha, self.encoder.fc_beta) if self.prior == "beta" else
+                  (self.encoder.fc_mu, self.encoder.fc_sigma[0]))
         joint = {}  # (id(leaf), pname) -> (joint key, joint shape, axis, start, length)
         n_mu, n_sig = fm.out_lib, fs.out_lib
         for leaf, start, length in ((fm, 0, n_mu), (fs, n_mu, n_sig)):
@@ -413,7 +418,7 @@ class ResVAE(nn.Module):
     def _heads_pieces(self):
         """Arithmetic of the joint fc_mu || fc_sigma GEMM: with a diagonal factor it is skinny (2 z columns over a deep reduction) --
         the fp32 split-K kernels whatever the batch; a full Cholesky factor (z (z + 3) / 2 columns) follows the model's precision."""
-        return 0 if self.is_diag else None
+        return 0 if (self.is_diag or self.prior == "beta") else None
 
     def _new_pass(self):
         """Start of forward / encode / decode: the master weights may have changed since the last pass, so
@@ -789,7 +794,29 @@ class ResVAE(nn.Module):
         self._lin("fc_heads", hd, B, pieces=self._heads_pieces()).fwd(flat, hd.weight, hd.bias, h)
         return B, flat, h
 
+    def _heads_beta(self, B, h, draw):
+        """prior = "beta": alpha, beta, mu (the rescaled mode) and the KL partials from one kernel; the draw x ~ Beta(alpha, beta) is
+        `draw` (data["eps"]: injected) or torch's sampler (RNG plumbing, like randn for the Gaussian heads); z = 2 x - 1 in train
+        AND eval mode (residual.py:328-331)."""
+        zp = pad16(self.z_dim)
+        zcp = pad16(self.z_dim + self.conditional_dim)
+        mu = self._buf("mu", (B, zp), zero=True)
+        alpha, beta = self._buf("alpha", (B, zp), zero=True), self._buf("beta", (B, zp), zero=True)
+        zc = self._buf("dec.zc", (B, zcp), zero=True)
+        klp = self._buf("kl_part", (ops.heads_blocks(B, self.z_dim),))
+        ops.heads_beta_fwd(h, self._hw, alpha, beta, mu, zp, klp, B, self.z_dim, zp)
+        a, b = alpha[:, : self.z_dim], beta[:, : self.z_dim]
+        if draw is None:
+            draw = torch._sample_dirichlet(torch.stack([a, b], -1))[..., 0]
+        x = self._buf("beta.x", (B, self.z_dim))
+        x.copy_(draw)
+        zc[:, : self.z_dim] = x * 2 - 1
+        self._L = None
+        return mu, (alpha, beta, x), zc, klp
+
     def _heads(self, B, h, eps):
+        if self.prior == "beta":
+            return self._heads_beta(B, h, eps)
         zp = pad16(self.z_dim)
         zcp = pad16(self.z_dim + self.conditional_dim)
         mu = self._buf("mu", (B, zp), zero=True)
@@ -896,6 +923,13 @@ class ResVAE(nn.Module):
         self._new_pass()
         self._ov = self._overlap_level(data["x6d"].shape[0])
         B, flat, h = self._encode_trunk(data)
+        if self.prior == "beta":  # residual.py:449-456: alpha, beta and the rescaled mode (encode draws nothing)
+            zp = pad16(self.z_dim)
+            mu = self._buf("mu", (B, zp), zero=True)
+            alpha, beta = self._buf("alpha", (B, zp), zero=True), self._buf("beta", (B, zp), zero=True)
+            ops.heads_beta_fwd(h, self._hw, alpha, beta, mu, zp, self._buf("kl_part", (ops.heads_blocks(B, self.z_dim),)), B, self.z_dim, zp)
+            self._state = dict(B=B, flat=flat, h=h, eps=None)
+            return {"alpha": alpha[:, : self.z_dim], "beta": beta[:, : self.z_dim], "mu": mu[:, : self.z_dim]}
         mu, sigma, zc, klp = self._heads(B, h, None)
         self._state = dict(B=B, flat=flat, h=h, eps=None)
         return {"mu": mu[:, : self.z_dim], "L": self._L_out(sigma)}
@@ -931,10 +965,17 @@ class ResVAE(nn.Module):
         self._ov = self._overlap_level(data["x6d"].shape[0])
         B, flat, h = self._encode_trunk(data)
         eps = None
-        if self.training:
+        if self.prior == "beta":  # data["eps"] = an injected draw x in (0, 1); else torch's sampler inside _heads_beta
+            eps = self._prep(data["eps"]) if "eps" in data else None
+        elif self.training:
             eps = self._prep(data["eps"]) if "eps" in data else self.sampling_noise(B)
         mu, sigma, zc, klp = self._heads(B, h, eps)
-        data_o = {"mu": mu[:, : self.z_dim], "L": self._L_out(sigma)}
+        if self.prior == "beta":
+            alpha, beta, eps = sigma  # (eps = the draw: what the backward differentiates implicitly)
+            data_o = {"alpha": alpha[:, : self.z_dim], "beta": beta[:, : self.z_dim], "mu": mu[:, : self.z_dim]}
+            data_o["beta_dist"] = torch.distributions.Beta(data_o["alpha"], data_o["beta"])
+        else:
+            data_o = {"mu": mu[:, : self.z_dim], "L": self._L_out(sigma)}
         data_o["z"] = zc[:, : self.z_dim]
         if self.conditional_dim > 0:
             data_o["var"] = self._conditional_var(data, B)
@@ -1170,7 +1211,10 @@ class ResVAE(nn.Module):
         # ---- heads: dh = [dmu | draw]
         h = st["h"]
         dh = self._buf("g.h", (B, self._hw), zero=True)
-        if self.is_diag:
+        if self.prior == "beta":
+            alpha, beta, _ = st["sigma"]
+            ops.heads_beta_bwd(h, self._hw, st["eps"], alpha, beta, zp, g_zc, zcp, d_mu, pend["kl_scale"], dh, B, self.z_dim, zp)
+        elif self.is_diag:
             ops.heads_diag_bwd(h, self._hw, st["eps"], st["sigma"], g_zc, zcp, d_mu, pend.get("dsigma"), pend["kl_scale"], dh, B,
                                self.z_dim, raw_off=zp, ldm=zp)
         else:

@@ -684,6 +684,16 @@ def heads_tril_bwd(h, ld, eps, L, dz, lddz, dmu, ldm, kl_scale, dlv, dh, batch, 
                                          batch, zdim, raw_off, _stream()), "heads_tril_bwd")
 
 
+def heads_beta_fwd(h, ld, alpha, beta, mu, ldm, kl_part, batch, zdim, raw_off):
+    check(_lib.lib().svae_heads_beta_fwd(_p(h), ld, _p(alpha), _p(beta), _p(mu), ldm, _p(kl_part), batch, zdim, raw_off, _stream()),
+          "heads_beta_fwd")
+
+
+def heads_beta_bwd(h, ld, x, alpha, beta, ldm, dz, lddz, dmu, kl_scale, dh, batch, zdim, raw_off):
+    check(_lib.lib().svae_heads_beta_bwd(_p(h), ld, _p(x), _p(alpha), _p(beta), ldm, _p(dz), lddz, _p(dmu), float(kl_scale), _p(dh),
+                                         batch, zdim, raw_off, _stream()), "heads_beta_bwd")
+
+
 def tc_logvar(sigma, lds, L, lv, batch, zdim):
     check(_lib.lib().svae_tc_logvar(_p(sigma), lds, _p(L), _p(lv), batch, zdim, _stream()), "tc_logvar")
 

@@ -348,6 +348,8 @@ def get_batch_loss(model, data, data_o, loss_scale, disentangle_config, adv_perm
     # ---- total correlation (L5): O(B^2 z) estimator over the local batch, z detached
     dsigma = dlv = None
     if "total_correlation" in loss_scale:
+        if model.prior == "beta":
+            raise KeyError("L")  # the reference reads data_o["L"] here (losses.py:312-316): no such entry under prior="beta"
         if z > 128:
             raise NotImplementedError("total_correlation kernel supports z_dim <= 128")
         zc, zcp = st["zc"], st["zc"].shape[1]

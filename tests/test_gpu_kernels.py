@@ -851,3 +851,44 @@ def test_fused_ensemble_losses(ops, kind):
         total += lw[m] * float(l)
         assert relerr(dp[m].cpu()[:, :C], gs[m] * x.grad) < 2e-5
     assert abs(float(part.double().sum()) - total) <= 2e-5 * abs(total)
+
+
+@pytest.mark.parametrize("B,z,lo,hi", [(64, 8, 1.0, 4.0), (257, 32, 1.0, 12.0), (33, 5, 6.5, 40.0)])
+def test_heads_beta_vs_torch(ops, B, z, lo, hi):
+    """model.prior = "beta": alpha / beta / mu, KL(Beta || Beta(1, 1)) and the backward -- the implicit reparameterisation gradient of
+    the draw (torch's _dirichlet_grad), the KL gradient (trigamma) and the mode's -- against torch.distributions on the CPU in fp64,
+    over shapes that reach every branch of the piecewise gradient approximation (series near 0 / 1, both shapes > 6, rational)."""
+    g = torch.Generator().manual_seed(B + z)
+    # raw head outputs chosen so that alpha, beta = softplus(raw) + 1 cover [lo, hi]
+    tgt_a = lo + (hi - lo) * torch.rand(B, z, generator=g, dtype=torch.float64)
+    tgt_b = lo + (hi - lo) * torch.rand(B, z, generator=g, dtype=torch.float64)
+    inv = lambda t: torch.log(torch.expm1((t - 1).clamp_min(1e-3)))
+    ra, rb = inv(tgt_a).float().double().requires_grad_(True), inv(tgt_b).float().double().requires_grad_(True)
+    x = (torch.rand(B, z, generator=g, dtype=torch.float64) * 0.98 + 0.01).float().double()
+    x[0, :] = torch.linspace(1e-4, 1 - 1e-4, z, dtype=torch.float64).float().double()  # both ends of (0, 1)
+    a, b = F.softplus(ra) + 1, F.softplus(rb) + 1
+    mu = (a - 1 + 1e-8) / (a + b - 2 + 2e-8) * 2 - 1
+    zz = O._BetaRSample.apply(a, b, x) * 2 - 1
+    q = torch.distributions.Beta(a, b)
+    kl = torch.distributions.kl_divergence(q, torch.distributions.Beta(torch.ones_like(a), torch.ones_like(b))).sum()
+    gz, gm = torch.randn(B, z, generator=g, dtype=torch.float64), torch.randn(B, z, generator=g, dtype=torch.float64)
+    kls = 0.37
+    ((zz * gz).sum() + (mu * gm).sum() + kls * kl).backward()
+
+    zp = (z + 15) // 16 * 16
+    h = torch.zeros(B, 2 * zp)
+    h[:, :z], h[:, zp: zp + z] = ra.detach().float(), rb.detach().float()
+    h = h.cuda()
+    al, be, mud = (torch.zeros(B, zp, device="cuda") for _ in range(3))
+    klp = torch.empty(ops.heads_blocks(B, z), device="cuda")
+    ops.heads_beta_fwd(h, 2 * zp, al, be, mud, zp, klp, B, z, zp)
+    assert relerr(al[:, :z].cpu(), a.detach()) < 2e-6 and relerr(be[:, :z].cpu(), b.detach()) < 2e-6
+    assert relerr(mud[:, :z].cpu(), mu.detach()) < 5e-6
+    assert abs(float(klp.double().sum()) - float(kl)) < 1e-5 * abs(float(kl)) + 1e-5
+    dz = torch.zeros(B, zp); dz[:, :z] = gz.float(); dmu = torch.zeros(B, zp); dmu[:, :z] = gm.float()
+    dh = torch.full((B, 2 * zp), float("nan"), device="cuda")
+    ops.heads_beta_bwd(h, 2 * zp, x.float().cuda().contiguous(), al, be, zp, dz.cuda(), zp, dmu.cuda(), kls, dh, B, z, zp)
+    # the piecewise approximation is evaluated in fp64 here and (for its series branches) in fp32 by torch on fp32 inputs; against the
+    # fp64 evaluation of the same algorithm:
+    assert relerr(dh[:, :z].cpu(), ra.grad) < 2e-5, relerr(dh[:, :z].cpu(), ra.grad)
+    assert relerr(dh[:, zp: zp + z].cpu(), rb.grad) < 2e-5, relerr(dh[:, zp: zp + z].cpu(), rb.grad)

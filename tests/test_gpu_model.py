@@ -20,13 +20,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import scvae_oracle as O
-from tests.test_oracle_golden import SCENARIOS, load_fixture, rel, ARENA
+from tests.test_oracle_golden import SCENARIOS, load_fixture, rel, ARENA, out_keys
 
 
 def build_model(cfg, sd):
     from scrubvae_amd.get import model as get_model
     model_config = dict(type="rcnn", kernel=cfg.kernel, z_dim=cfg.z_dim, window=cfg.window, activation=cfg.activation,
-                        diag=cfg.diag, init_dilation=None, prior="gaussian", channel=list(cfg.channel))
+                        diag=cfg.diag, init_dilation=None, prior=cfg.prior, channel=list(cfg.channel))
     dis = dict(method=cfg.method, alpha=cfg.alpha, features=cfg.features or [])
     m = get_model(model_config, None, None, dis, cfg.n_keypts, "midfwd", arena_size=cfg.arena_size,
                   kinematic_tree=cfg.kinematic_tree, discrete_classes=cfg.discrete_classes, device="cuda", verbose=0)
@@ -41,7 +41,7 @@ def to_dev(data):
 
 @pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "rotation_tiny", "fullL_ids_tiny", "tc_tiny", "vanilla_default_B4",
                                   "w256_tiny", "w256_6blocks_tiny", "linear_gr_tiny", "tanh_tiny", "vanilla_default_j23_B4",
-                                  "full_j23_tiny"])
+                                  "full_j23_tiny", "beta_tiny", "beta_full_tiny"])
 def test_step0_matches_reference_fixture(golden_dir, name):
     from scrubvae_amd.train.losses import get_batch_loss
     fx, cfg, loss_scale, opt, sd, data = load_fixture(golden_dir, name)
@@ -56,7 +56,7 @@ def test_step0_matches_reference_fixture(golden_dir, name):
     data_o = model(d)
     perm = torch.from_numpy(fx["perm/0"])
     bl = get_batch_loss(model, d, data_o, loss_scale, dis, adv_perm={k: perm for k in cfg.method.get("adversarial_net", [])})
-    for k in ("mu", "L", "z", "x6d", "root"):
+    for k in out_keys(cfg):  # (prior="beta": alpha, beta in place of L; data["eps"] is then the injected Beta draw)
         assert rel(data_o[k].cpu(), fx["s0/out/" + k]) < 2e-5, k
     for k in fx.files:
         if k.startswith("s0/out/disentangle/"):
@@ -93,7 +93,7 @@ def test_step0_matches_reference_fixture(golden_dir, name):
     assert rel(gn, fx["s0/grad_norm"]) < (1e-2 if "rotation" in loss_scale else 1e-3)
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "linear_gr_tiny"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "linear_gr_tiny", "beta_tiny"])
 def test_grads_vs_fp64_truth(golden_dir, name):
     """HIP fp32 gradients against the fp64 oracle.  Forward outputs/losses are as accurate as the
     fp32 CPU path (measured 1.3x / 1.0x its error); gradients are cancellation-prone sums and
@@ -128,7 +128,7 @@ def test_grads_vs_fp64_truth(golden_dir, name):
     assert worst_hip < 12 * worst_cpu + 1e-3, (worst_hip, worst_cpu)
 
 
-@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "linear_gr_tiny", "full_j23_tiny"])
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "linear_gr_tiny", "full_j23_tiny", "beta_tiny"])
 def test_three_steps_and_eval(golden_dir, name):
     """trainer-style loop (fused AdamW) for 3 steps, then eval-mode forward; same gates as the
     oracle's own multi-step test (Adam amplifies fp32 noise)."""
@@ -165,6 +165,7 @@ def test_three_steps_and_eval(golden_dir, name):
             # either -- bit-unchanged after the three steps, in the reference and here
             assert torch.equal(new_sd[k[9:]].cpu(), torch.from_numpy(fx[k])) and torch.equal(sd[k[9:]], torch.from_numpy(fx[k])), k
     model.eval()
+    d["eps"] = torch.from_numpy(fx["eps/0"]).cuda()  # (only prior="beta" draws in eval mode: the fixture's eval pass used draw 0)
     with torch.no_grad():
         data_o = model(d)
         bl = get_batch_loss(model, d, data_o, loss_scale, dis,
@@ -470,7 +471,7 @@ def bf16x6_everywhere(request):
 
 
 @pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "fullL_ids_tiny", "vanilla_default_B4", "w256_6blocks_tiny", "tanh_tiny",
-                                  "vanilla_default_j23_B4", "full_j23_tiny"])
+                                  "vanilla_default_j23_B4", "full_j23_tiny", "beta_full_tiny"])
 def test_step0_matches_reference_fixture_bf16x6(golden_dir, name, bf16x6_everywhere):
     """The reference fixtures at the SAME fp32 tolerances with the contractions on the bf16 matrix cores
     (bench.py's default precision): the 3-piece split is fp32-accurate, not a reduced-precision mode."""
