@@ -221,8 +221,9 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
     for (int k = 0; k < 6; ++k) a6[k] = my[k];
     M0 = c6_to_mat(a6);
   }
+  M3 Rc = M0;  // the chain's running rotation product; after phase 1: through the chain's LAST joint (phase 3 walks it back)
   if (active && chain_wave) {
-    M3 R = M0;
+    M3& R = Rc;
     float acc[3] = {0.f, 0.f, 0.f};
     for (int i = 1; i < len; ++i) {
       const int j = g.tree.chain[ch][i];
@@ -316,17 +317,12 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
 #pragma unroll
   for (int k = 0; k < 9; ++k) carry.m[k] = 0.f;
   if (do_bwd && active && chain_wave) {
-    M3 Rs[SVAE_MAX_CHAIN_LEN - 1];
-    Rs[0] = M0;
-#pragma unroll
-    for (int i = 1; i < SVAE_MAX_CHAIN_LEN - 1; ++i) {
-      if (i < len - 1) {
-        const int j = g.tree.chain[ch][i];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) a6[k] = my[6 * j + k];
-        Rs[i] = mul(Rs[i - 1], c6_to_mat(a6));
-      }
-    }
+    // The backward of joint i needs the prefix product P_{i-1} = M_0 M_c1 ... M_c(i-1).  Keeping all of them (an array of up to 7
+    // matrices, 63 registers) put the kernel at 194 VGPRs -- one 6-wave workgroup per CU.  They are walked BACK instead from the
+    // full product phase 1 left in Rc:  P_{i-1} = P_i M_ci^-1, and M^-1 = diag(1 / |column|^2) M^T because the columns of a
+    // cont6d matrix are mutually orthogonal by construction (x, z = x x b / |.|, y = z x x) and differ from unit length only by the
+    // eps of the normalisations: one extra 3x3 product per joint, rounding-level differences (<= 1e-6) in the gradients.
+    M3 P = Rc;
 #pragma unroll
     for (int i = SVAE_MAX_CHAIN_LEN - 1; i >= 1; --i) {
       if (i < len) {
@@ -339,7 +335,19 @@ __global__ __launch_bounds__(64 * SVAE_MAX_CHAINS) void pose_tail_kernel(const T
 #pragma unroll
         for (int k = 0; k < 6; ++k) a6[k] = my[6 * j + k];
         const M3 Mj = c6_to_mat(a6);
-        const M3 dMj = mul_tn(Rs[i - 1], D);
+        {  // P <- P Mj^-1 (prefix product up to the joint in front of j)
+          float inv[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) inv[c] = 1.f / (Mj.m[c] * Mj.m[c] + Mj.m[3 + c] * Mj.m[3 + c] + Mj.m[6 + c] * Mj.m[6 + c]);
+          M3 Q;
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)  // (P Mj^-1)[r][k] = sum_c P[r][c] inv[c] Mj[k][c]
+              Q.m[r * 3 + k] = P.m[r * 3] * inv[0] * Mj.m[k * 3] + P.m[r * 3 + 1] * inv[1] * Mj.m[k * 3 + 1] + P.m[r * 3 + 2] * inv[2] * Mj.m[k * 3 + 2];
+          P = Q;
+        }
+        const M3 dMj = mul_tn(P, D);
         carry = mul_nt(D, Mj);
         float da[6];
         c6_to_mat_bwd(a6, dMj, da);
