@@ -4,8 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from scrubvae_amd import ops
 B = int(os.environ.get("B", 1024))
+MID = [("dec1.sk", 14, 512, 256, 6, 1, 2, False), ("dec0.t2", 4, 512, 512, 5, 2, 2, True), ("enc3.c0", 8, 512, 512, 5, 2, 2, False),
+       ("dec2.sk", 26, 256, 128, 6, 1, 2, False), ("dec1.t1", 7, 512, 256, 5, 1, 2, True), ("enc1.sk", 32, 128, 256, 5, 2, 2, False),
+       ("dec3.sk", 50, 128, 64, 6, 1, 2, False), ("dec2.t1", 13, 256, 128, 5, 1, 2, True)]  # LAYERS=mid: the mid-size data-gradients
 LAYERS = [("enc3.c3", 4, 512, 1024, 5, 1, 2, False), ("dec0.sk", 8, 1024, 512, 6, 1, 2, False), ("dec0.t1", 4, 1024, 512, 5, 1, 2, True),
           ("enc2.c3", 8, 256, 512, 5, 1, 2, False), ("dec1.sk", 14, 512, 256, 6, 1, 2, False), ("enc1.c3", 16, 128, 256, 5, 1, 2, False)]
+if os.environ.get("LAYERS") == "mid":
+    LAYERS = MID
 codes = [int(c) for c in sys.argv[1:]] or [8128128, 9128128]
 COLD = os.environ.get("COLD", "0") != "0"
 _flush = None
