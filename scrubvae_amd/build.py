@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["capi.hip", "gemm_f32.hip", "gemm_bf16s.hip", "elementwise.hip", "pose_tail.hip", "latent.hip", "preprocess.hip", "ensemble.hip"]
+SOURCES = ["capi.hip", "gemm_f32.hip", "gemm_bf16s.hip", "halo_ws_bf16s.hip", "wgrad_bf16s.hip", "elementwise.hip", "pose_tail.hip", "latent.hip", "preprocess.hip", "ensemble.hip"]
 OUT = os.path.join(CSRC, "libscrubvae_hip.so")
 
 
@@ -12,7 +12,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + ["svae_internal.h", "gemm_common.h"]]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + ["svae_internal.h", "gemm_common.h", "split_common.h", "split_gather.h"]]
     deps.append(os.path.join(CSRC, "..", "..", "include", "scrubvae_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -26,7 +26,7 @@ def build(force=False, verbose=False, ablation=False):
     from concurrent.futures import ThreadPoolExecutor
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "svae_internal.h"), os.path.join(CSRC, "gemm_common.h"),
+    headers = [os.path.join(CSRC, "svae_internal.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "split_common.h"), os.path.join(CSRC, "split_gather.h"),
                os.path.join(CSRC, "..", "..", "include", "scrubvae_hip.h")]
     hdr_t = max(os.path.getmtime(h) for h in headers)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + (["-DSVAE_ABLATION_KERNELS"] if ablation else [])

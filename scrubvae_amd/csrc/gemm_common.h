@@ -164,10 +164,10 @@ struct WgradArgs {
   int accumulate;
   int xmap;  // split-bf16 kernel: XCD-aware workgroup order (tile code variants 2 / 3)
   int flat_mp;  // split-bf16 kernel, > 0: the taps are folded into the X channels (M = T * flat_mp: convs, dY rows tap-independent; variant bit 16)
-  int flat_np;  // split-bf16 kernel, > 0: the taps are folded into the dY columns (N = T * flat_np, variant bit 16; see gemm_bf16s.hip)
+  int flat_np;  // split-bf16 kernel, > 0: the taps are folded into the dY columns (N = T * flat_np, variant bit 16; see wgrad_bf16s.hip)
 };
 
-// all-taps split-bf16 weight-gradient kernel (gemm_bf16s.hip): grid (row tiles, column tiles, splits)
+// all-taps split-bf16 weight-gradient kernel (wgrad_bf16s.hip): grid (row tiles, column tiles, splits)
 struct WgradTapsArgs {
   const float* S;       // shifted operand (x of a conv, dY of a transposed conv): row b Ls + j ss + t dil - pad
   const float* F;       // fixed operand (dY of a conv, x of a transposed conv): row b nj + j
@@ -180,7 +180,7 @@ struct WgradTapsArgs {
   int srows;   // image rows of a stage: (32 - 1) ss + T + max(e, 0) * (sample boundaries a stage can cross)
 };
 int launch_wgrad_taps(const WgradTapsArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int trans_out, int m16);
-// split-bf16 weight-gradient main kernel (gemm_bf16s.hip); same grid / slabs as wgrad_gemm_kernel
+// split-bf16 weight-gradient main kernel (wgrad_bf16s.hip); same grid / slabs as wgrad_gemm_kernel
 int launch_wgrad_split(const WgradArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int pieces, int variant);
 
 }  // namespace svae

@@ -1038,7 +1038,7 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
     w.nsplit = (int)((w.R + w.rps - 1) / w.rps);
     return w;
   }
-  if ((d->tile[2] / 1000000) & 4) {  // all-taps split-bf16 kernel (gemm_bf16s.hip): one workgroup per tile of ALL taps
+  if ((d->tile[2] / 1000000) & 4) {  // all-taps split-bf16 kernel (wgrad_bf16s.hip): one workgroup per tile of ALL taps
     Tile tv;
     if (!decode_tile(d->tile[2] % 1000000, tv)) { tv.bm = 128; tv.bn = 128; }
     w.bm = tv.bm; w.bn = tv.bn;
@@ -1064,7 +1064,7 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
   Tile ov;
   const int tcode = d->tile[2] > 0 ? d->tile[2] % 1000000 : 0;
   const bool flat = d->tile[2] > 0 && ((d->tile[2] / 1000000) & 16) && !((d->tile[2] / 1000000) & 4);  // taps folded into the dY columns
-  const bool big = tcode == 256256 || tcode == 256128 || tcode == 128256;  // 8-wave split-bf16 tiles (gemm_bf16s.hip)
+  const bool big = tcode == 256256 || tcode == 256128 || tcode == 128256;  // 8-wave split-bf16 tiles (wgrad_bf16s.hip)
   if (big) {
     w.bm = tcode / 1000; w.bn = tcode % 1000;
     w.ctiles = (d->c_in + w.bm - 1) / w.bm;

@@ -9,8 +9,13 @@ MID = [("dec1.sk", 14, 512, 256, 6, 1, 2, False), ("dec0.t2", 4, 512, 512, 5, 2,
        ("dec3.sk", 50, 128, 64, 6, 1, 2, False), ("dec2.t1", 13, 256, 128, 5, 1, 2, True)]  # LAYERS=mid: the mid-size data-gradients
 LAYERS = [("enc3.c3", 4, 512, 1024, 5, 1, 2, False), ("dec0.sk", 8, 1024, 512, 6, 1, 2, False), ("dec0.t1", 4, 1024, 512, 5, 1, 2, True),
           ("enc2.c3", 8, 256, 512, 5, 1, 2, False), ("dec1.sk", 14, 512, 256, 6, 1, 2, False), ("enc1.c3", 16, 128, 256, 5, 1, 2, False)]
+S2 = [("enc3.sk", 8, 512, 1024, 5, 2, 2, False), ("enc3.c0", 8, 512, 512, 5, 2, 2, False), ("enc2.sk", 16, 256, 512, 5, 2, 2, False),
+      ("enc2.c0", 16, 256, 256, 5, 2, 2, False), ("enc1.sk", 32, 128, 256, 5, 2, 2, False), ("dec0.t2", 4, 512, 512, 5, 2, 2, True),
+      ("dec1.t2", 7, 256, 256, 5, 2, 2, True)]  # LAYERS=s2: the stride-2 layers (parity phases in the data-gradient / transposed forward)
 if os.environ.get("LAYERS") == "mid":
     LAYERS = MID
+if os.environ.get("LAYERS") == "s2":
+    LAYERS = S2
 codes = [int(c) for c in sys.argv[1:]] or [8128128, 9128128]
 COLD = os.environ.get("COLD", "0") != "0"
 _flush = None
