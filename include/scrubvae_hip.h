@@ -64,6 +64,13 @@ typedef struct {
    * the LDS-DMA staging variant (global_load_lds, XOR-swizzled LDS image).  tile[2] = 1 selects the tap-fused
    * small-weight gradient kernel (64x64 tiles, all taps of a tile in one workgroup). */
   int tile[3];
+  /* 1: the conv's input is nn.Upsample(scale_factor=2, mode="linear", align_corners=False) of a [batch, l_in / 2, c_in] tensor
+   * (the decoder's skip path, residual.py:160): l_in stays the UPSAMPLED length, x points to the half-length tensor, and the
+   * forward (svae_conv_fwd_split*, halo tile codes 8 / 9) and weight-gradient (svae_conv_wgrad_split, all-taps tile codes) kernels
+   * blend its rows while they stage the operand -- the upsampled tensor need not exist.  nn.Conv1d with stride 1 only; the fp32
+   * entry points and the other tile codes return SVAE_ERR_SHAPE.  The data-gradient entry points ignore the flag: dx is the
+   * gradient with respect to the upsampled input (fold it back with svae_upsample2_bwd).  0 elsewhere. */
+  int up2;
 } svae_conv_desc;
 
 /* y[b,lo,:] (+)= bias + sum_t x[b,li(lo,t),:] @ w[t]     (residual.py:79-109,137-170,
@@ -126,6 +133,12 @@ int svae_conv_fwd_split(const svae_conv_desc* d, const float* x, const void* wsp
 int svae_conv_fwd_stats_tiles(const svae_conv_desc* d);
 int svae_conv_fwd_split_stats(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias,
                               float* y, int accumulate, int pieces, float* bn_part, void* stream);
+/* The same launch for a descriptor with up2 = 1 (conv behind nn.Upsample(x2, linear): residual.py:153-170) that additionally
+ * writes the upsampled operand rows it blends to up_out[batch * l_in][c_in] (each row once; ld_in == c_in) -- the tensor the
+ * conv's weight gradient reads in the backward pass -- so that no separate svae_upsample2_fwd launch (one more read of x) is
+ * needed.  up_out = NULL: nothing is written; bn_part as above (NULL: off). */
+int svae_conv_fwd_split_up2(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias,
+                            float* y, int accumulate, int pieces, float* bn_part, float* up_out, void* stream);
 int svae_conv_dgrad_split(const svae_conv_desc* d, const float* dy, const void* wsplit, float* dx,
                           int accumulate, int pieces, void* stream);
 /* The same launch when dx is the gradient with respect to the OUTPUT of a BatchNorm1d + PReLU / Tanh stage (the `add` / `residual.1-2`

@@ -17,7 +17,7 @@ MAX_TAPS, MAX_JOINTS, MAX_CHAINS, MAX_CHAIN_LEN = 128, 32, 8, 8
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "batch", "l_in", "l_out", "c_in", "c_out", "ld_in", "ld_out",
-        "kernel", "stride", "padding", "dilation", "transposed")] + [("tile", C.c_int * 3)]
+        "kernel", "stride", "padding", "dilation", "transposed")] + [("tile", C.c_int * 3), ("up2", C.c_int)]
 
 
 class ColsumTask(C.Structure):
@@ -103,6 +103,7 @@ SIGNATURES = {
     "svae_conv_fwd_split": (I, [DP, P, P, P, P, I, I, P]),
     "svae_conv_fwd_stats_tiles": (I, [DP]),
     "svae_conv_fwd_split_stats": (I, [DP, P, P, P, P, I, I, P, P]),
+    "svae_conv_fwd_split_up2": (I, [DP, P, P, P, P, I, I, P, P, P]),
     "svae_conv_dgrad_split": (I, [DP, P, P, P, I, I, P]),
     "svae_conv_dgrad_stats_tiles": (I, [DP, C.POINTER(I)]),
     "svae_conv_dgrad_split_bn": (I, [DP, P, P, P, I, I, C.POINTER(BnBwdFuse), P]),

@@ -481,7 +481,10 @@ __global__ __launch_bounds__(64 * (4 + CWR * CWC)) void gather_gemm_bf16s_ws_ker
 // that a tap reaches across a sample boundary (conv padding) hold the neighbouring sample's data
 // and are zeroed in registers by the reader.  A-side global loads, split VALU and LDS writes drop
 // by ~k.  K loop order: channel block outer, tap inner.
-template <int BM, int BN, int P, int WR, int WC, int RMAX, bool H = false>
+// UP: the gathered operand is the x2 linear upsample (align_corners = false; reference residual.py:160, the decoder's skip path) of
+// the half-length tensor g.A points to: image row (b, ro) = 0.75 x[b, ro / 2] + 0.25 x[b, ro / 2 -/+ 1] (clamped at the sample's
+// ends) is blended from two source rows on its way into LDS -- the upsampled tensor never exists in HBM.
+template <int BM, int BN, int P, int WR, int WC, int RMAX, bool H = false, bool UP = false>
 __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const SplitGatherArgs sa) {
   const GatherArgs& g = sa.g;
   constexpr int NTH = 64 * WR * WC;
@@ -528,13 +531,30 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
   // ---- A image staging: 8 lanes per row, RPP rows per pass
   const int akq = tid & 7;
   long long a_goff[APASS];
+  long long a_goff2[UP ? APASS : 1];
   bool a_row_ok[APASS];
+  bool up_store[UP ? APASS : 1];
+  long long own_end = 0;  // UP: this tile owns the upsampled rows [amin, own_end): up to the next tile's first anchor / the end of the tensor
+  if constexpr (UP) {
+    const long long mn = m0 + BM;
+    if (mn < Mp) { const long long bn_ = mn / nj; own_end = bn_ * g.Lin + (mn - bn_ * nj) * g.sj; }
+    else own_end = sa.rowsA;
+  }
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
     const int r = (tid >> 3) + RPP * i;
     const long long grow = gbase + r;
     a_row_ok[i] = r < R && grow >= 0 && grow < sa.rowsA;
-    a_goff[i] = (a_row_ok[i] ? grow : 0) * (long long)g.ldA;
+    if constexpr (UP) {
+      up_store[i] = sa.up_out != nullptr && blockIdx.y == 0 && a_row_ok[i] && grow >= amin && grow < own_end;
+      const long long gr = a_row_ok[i] ? grow : 0, b = gr / g.Lin;
+      const int ro = (int)(gr - b * g.Lin), L = g.Lin >> 1, ii = ro >> 1;
+      const int i2 = (ro & 1) ? (ii + 1 < L ? ii + 1 : L - 1) : (ii > 0 ? ii - 1 : 0);
+      a_goff[i] = (b * L + ii) * (long long)g.ldA;
+      a_goff2[i] = (b * L + i2) * (long long)g.ldA;
+    } else {
+      a_goff[i] = (a_row_ok[i] ? grow : 0) * (long long)g.ldA;
+    }
   }
   if (tid < BM) {
     const long long m = m0 + tid;
@@ -563,15 +583,19 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
   const int ns = ntaps * sa.KB;
 
   float4 ra[APASS];
+  float4 ra2[UP ? APASS : 1];
   bool ra_ok[APASS];
   uint4 rb[BPASS];
+  int st_c = 0;  // UP: channel offset of the values load_a fetched last (store_a's by-product store)
   auto load_a = [&](int kb) {
     const int c0 = kb * SBK;
     const bool kq_ok = c0 + akq * 4 < g.Kc;
     const int cq = kq_ok ? c0 + akq * 4 : 0;
+    if constexpr (UP) st_c = cq;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       ra[i] = *reinterpret_cast<const float4*>(g.A + a_goff[i] + cq);
+      if constexpr (UP) ra2[i] = *reinterpret_cast<const float4*>(g.A + a_goff2[i] + cq);
       ra_ok[i] = a_row_ok[i] && kq_ok;
     }
   };
@@ -580,7 +604,15 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
     for (int i = 0; i < APASS; ++i) {
       const int r = (tid >> 3) + RPP * i;
       uint2 pc[P];
-      split4x<P, H>(ra_ok[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f), pc);
+      float4 v = ra[i];
+      if constexpr (UP) {
+        const float4 q = ra2[i];
+        v = make_float4(0.75f * v.x + 0.25f * q.x, 0.75f * v.y + 0.25f * q.y, 0.75f * v.z + 0.25f * q.z, 0.75f * v.w + 0.25f * q.w);
+        // by-product: the upsampled rows this tile OWNS (first row's anchor up to the next tile's) go to sa.up_out -- the operand of the
+        // conv's weight gradient in the backward pass -- from the first column tile only; halo rows belong to the neighbours
+        if (up_store[i] && ra_ok[i]) *reinterpret_cast<float4*>(sa.up_out + (gbase + r) * (long long)g.ldA + st_c) = v;
+      }
+      split4x<P, H>(ra_ok[i] ? v : make_float4(0.f, 0.f, 0.f, 0.f), pc);
       const int off = r * ROWB + (((akq >> 1) ^ swz(r)) << 4) + ((akq & 1) << 3);
       if ((i + 1) * RPP <= RMAX || r < RMAX) {
 #pragma unroll
@@ -838,6 +870,13 @@ template <int BN>
 static int launch_halo(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
   if (pieces != 3 && pieces != 2 && pieces != SVAE_PIECES_F16X2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
   if (rows > 264) { set_error("split gather: halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
+  if (sa.g.up) {  // fused x2 upsample of the gathered operand
+#define SVAE_HUP(P_, H_) do { if (rows <= 160) hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, P_, 4, 2, 160, H_, true>), grid, dim3(512), 0, st, sa); \
+                              else hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, P_, 4, 2, 264, H_, true>), grid, dim3(512), 0, st, sa); } while (0)
+    if (pieces == SVAE_PIECES_F16X2) SVAE_HUP(2, true); else if (pieces == 3) SVAE_HUP(3, false); else SVAE_HUP(2, false);
+#undef SVAE_HUP
+    return SVAE_OK;
+  }
   if (pieces == SVAE_PIECES_F16X2) {
     if (rows <= 160) hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 2, 4, 2, 160, true>), grid, dim3(512), 0, st, sa);
     else hipLaunchKernelGGL((gather_halo_bf16s_kernel<128, BN, 2, 4, 2, 264, true>), grid, dim3(512), 0, st, sa);
@@ -857,6 +896,13 @@ template <int BN>
 static int launch_halo256(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
   if (pieces != 3 && pieces != 2 && pieces != SVAE_PIECES_F16X2) { set_error("split gather: the halo kernel is built for 2 or 3 pieces"); return SVAE_ERR_SHAPE; }
   if (rows > 528 || (pieces == 3 && rows > 320 && BN > 64)) { set_error("split gather: 256-row halo image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
+  if (sa.g.up) {  // fused x2 upsample of the gathered operand (images of up to 320 rows: 6-tap convs on 256-row tiles need 298)
+    if (rows > 320) { set_error("split gather: the fused upsample exists for 256-row halo images of <= 320 rows (%d)", rows); return SVAE_ERR_SHAPE; }
+    if (pieces == SVAE_PIECES_F16X2) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 2, 4, 2, 320, true, true>), grid, dim3(512), 0, st, sa);
+    else if (pieces == 3) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 3, 4, 2, 320, false, true>), grid, dim3(512), 0, st, sa);
+    else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 2, 4, 2, 320, false, true>), grid, dim3(512), 0, st, sa);
+    return SVAE_OK;
+  }
   if (pieces == SVAE_PIECES_F16X2) {
     if (rows <= 320) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 2, 4, 2, 320, true>), grid, dim3(512), 0, st, sa);
     else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, BN, 2, 4, 2, 528, true>), grid, dim3(512), 0, st, sa);
@@ -893,8 +939,12 @@ static int launch_halo256_wide(const SplitGatherArgs& sa, dim3 grid, hipStream_t
 static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, int pieces) {
   GatherArgs& g = sa.g;
   Tile t;
-  if (!decode_tile(code, t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
+  if (!decode_tile(code, t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; if (g.up) { t.bm = 128; t.dma = 8; } }
   const int v = t.dma;
+  if (g.up && v != 8 && v != 9) {
+    set_error("split gather: the fused x2 upsample of the input exists in the halo kernels (tile codes 8 / 9), not in code %d", code);
+    return SVAE_ERR_SHAPE;
+  }
   if (v >= 10 && v != 19) {
     bool handled = false;
     const int e = launch_split_halo_ws(sa, st, t, code, pieces, &handled);
@@ -979,7 +1029,7 @@ extern "C" int svae_conv_fwd_stats_tiles(const svae_conv_desc* d) {
   g.N = d->c_out;
   build_plan(g, d, !d->transposed, d->l_out, d->l_in);
   Tile t;
-  if (!decode_tile(d->tile[0], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
+  if (!decode_tile(d->tile[0], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; if (d->up2) { t.bm = 128; t.dma = 8; } }  // as launch_split_gather
   const int bm = (t.dma == 9 || t.dma == 11 || t.dma >= 13) ? 256 : t.bm;
   return (int)((g.M[0] + bm - 1) / bm + (g.M[1] + bm - 1) / bm);
 }
@@ -991,7 +1041,14 @@ extern "C" int svae_conv_fwd_split(const svae_conv_desc* d, const float* x, cons
 
 extern "C" int svae_conv_fwd_split_stats(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias, float* y,
                                          int accumulate, int pieces, float* bn_part, void* stream) {
+  return svae_conv_fwd_split_up2(d, x, wsplit, bias, y, accumulate, pieces, bn_part, nullptr, stream);
+}
+
+extern "C" int svae_conv_fwd_split_up2(const svae_conv_desc* d, const float* x, const void* wsplit, const float* bias, float* y,
+                                       int accumulate, int pieces, float* bn_part, float* up_out, void* stream) {
   if (int e = validate(d)) return e;
+  SVAE_REQUIRE(up_out == nullptr || (d->up2 && aligned16(up_out) && d->ld_in == d->c_in), SVAE_ERR_ARG,
+               "conv_fwd_split_up2: up_out needs an up2 descriptor with ld_in == c_in and a 16-byte aligned buffer");
   SVAE_REQUIRE(x && wsplit && y, SVAE_ERR_ARG, "conv_fwd_split: null pointer");
   SVAE_REQUIRE(aligned16(x) && aligned16(wsplit) && aligned16(y), SVAE_ERR_ALIGN, "conv_fwd_split: pointers must be 16-byte aligned");
   SVAE_REQUIRE((pieces >= 1 && pieces <= 3) || pieces == SVAE_PIECES_F16X2, SVAE_ERR_ARG, "conv_fwd_split: pieces %d not in 1..3 / 22", pieces);
@@ -1008,6 +1065,8 @@ extern "C" int svae_conv_fwd_split_stats(const svae_conv_desc* d, const float* x
   g.N = d->c_out;
   g.accumulate = accumulate;
   g.stats = bn_part;
+  g.up = d->up2;
+  sa.up_out = up_out;
   build_plan(g, d, /*strided=*/!d->transposed, d->l_out, d->l_in);
   return launch_split_gather(sa, (hipStream_t)stream, d->tile[0], pieces);
 }
@@ -1067,7 +1126,7 @@ extern "C" int svae_conv_split_tile(const svae_conv_desc* d, int kind, int* bm, 
   if (kind == 0) { g.N = d->c_out; build_plan(g, d, !d->transposed, d->l_out, d->l_in); }
   else { g.N = d->c_in; build_plan(g, d, d->transposed != 0, d->l_in, d->l_out); }
   Tile t;
-  if (!decode_tile(d->tile[kind], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
+  if (!decode_tile(d->tile[kind], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; if (d->up2 && kind == 0) { t.bm = 128; t.dma = 8; } }
   *bm = t.bm; *bn = t.bn; *variant = t.dma; *rmax = 0;
   if (t.dma == 8) { const int r = halo_rows(g, 128); *rmax = r <= 160 ? 160 : 264; }
   if (t.dma == 9) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 320 ? 320 : 528; }

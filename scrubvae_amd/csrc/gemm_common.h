@@ -21,6 +21,7 @@ struct GatherArgs {
   int blocks_m[2];
   int Lin, Lout, sj, n_phase;
   int Kc;  // reduction channels per tap, multiple of 16
+  int up;  // 1 (forward of a conv behind nn.Upsample(x2, linear)): A points to the HALF-length tensor [batch][Lin / 2][ldA]; the gathered operand is its upsample (Lin rows per sample)
   int ldA, ldC, ldW;
   long long w_tap_stride;
   int N;  // padded output channels
@@ -62,6 +63,8 @@ inline int validate(const svae_conv_desc* d) {
   else
     expect = (d->l_in - 1) * d->stride - 2 * d->padding + d->dilation * (d->kernel - 1) + 1;
   SVAE_REQUIRE(expect == d->l_out, SVAE_ERR_SHAPE, "conv: l_out %d != formula %d", d->l_out, expect);
+  SVAE_REQUIRE(d->up2 == 0 || (d->up2 == 1 && !d->transposed && d->stride == 1 && d->l_in % 2 == 0), SVAE_ERR_SHAPE,
+               "conv: up2 (input = x2 linear upsample of a half-length tensor) needs a stride-1 nn.Conv1d geometry with an even l_in");
   return SVAE_OK;
 }
 
@@ -178,6 +181,8 @@ struct WgradTapsArgs {
   int accumulate, xmap;
   int e;       // Ls - nj ss: rows a sample of S has beyond the contiguous geometry (0, +1: skip convs, -1: odd-length stride-2 convs)
   int srows;   // image rows of a stage: (32 - 1) ss + T + max(e, 0) * (sample boundaries a stage can cross)
+  unsigned up_inv;  // up: ceil(2^20 / Ls) (row -> (sample, position) by multiply-shift)
+  int up;      // 1: S points to the HALF-length tensor [batch][Ls / 2][Cs]; the kernel's shifted operand is its x2 linear upsample (Ls rows per sample)
 };
 int launch_wgrad_taps(const WgradTapsArgs& g, dim3 grid, hipStream_t st, int bm, int bn, int trans_out, int m16);
 // split-bf16 weight-gradient main kernel (wgrad_bf16s.hip); same grid / slabs as wgrad_gemm_kernel

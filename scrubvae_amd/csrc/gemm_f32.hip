@@ -938,6 +938,7 @@ using namespace svae;
 extern "C" int svae_conv_fwd(const svae_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                              int accumulate, void* stream) {
   if (int e = validate(d)) return e;
+  SVAE_REQUIRE(!d->up2, SVAE_ERR_SHAPE, "conv_fwd: the fused x2 upsample of the input (up2) exists in the split-precision halo kernels only");
   SVAE_REQUIRE(x && w && y, SVAE_ERR_ARG, "conv_fwd: null pointer");
   SVAE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), SVAE_ERR_ALIGN, "conv_fwd: pointers must be 16-byte aligned");
   GatherArgs g;
@@ -967,6 +968,7 @@ extern "C" size_t svae_conv_splitk_workspace(const svae_conv_desc* d, int kind) 
 extern "C" int svae_conv_fwd_ws(const svae_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                                 int accumulate, void* ws, size_t ws_bytes, void* stream) {
   if (int e = validate(d)) return e;
+  SVAE_REQUIRE(!d->up2, SVAE_ERR_SHAPE, "conv_fwd: the fused x2 upsample of the input (up2) exists in the split-precision halo kernels only");
   SVAE_REQUIRE(x && w && y, SVAE_ERR_ARG, "conv_fwd: null pointer");
   SVAE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(ws), SVAE_ERR_ALIGN, "conv_fwd: pointers must be 16-byte aligned");
   GatherArgs g;
@@ -1015,6 +1017,13 @@ extern "C" int svae_conv_dgrad(const svae_conv_desc* d, const float* dy, const f
 
 namespace svae {
 struct WgradGeo { int bm, bn, nsplit, nj, ctiles; long long rps, R; int fused, tg, tgroups; };
+
+// up2 convs exist on the all-taps kernels only: that is also what tile[2] = 0 (the built-in choice) means for them
+static inline svae_conv_desc wgrad_desc(const svae_conv_desc* d) {
+  svae_conv_desc e = *d;
+  if (e.up2 && e.tile[2] == 0) e.tile[2] = 4064128;
+  return e;
+}
 
 static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
   WgradGeo w;
@@ -1099,6 +1108,8 @@ static WgradGeo wgrad_geometry(const svae_conv_desc* d) {
 
 extern "C" size_t svae_conv_wgrad_workspace(const svae_conv_desc* d) {
   if (validate(d)) return 0;
+  const svae_conv_desc de = wgrad_desc(d);
+  d = &de;
   const WgradGeo wg = wgrad_geometry(d);
   const int nsplit = wg.nsplit;
   const long long rows = (long long)d->batch * d->l_out;
@@ -1110,6 +1121,8 @@ extern "C" size_t svae_conv_wgrad_workspace(const svae_conv_desc* d) {
 static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
                            size_t ws_bytes, int accumulate, void* stream, int pieces) {
   if (int e = validate(d)) return e;
+  const svae_conv_desc de = wgrad_desc(d);
+  d = &de;
   SVAE_REQUIRE(x && dy && dw, SVAE_ERR_ARG, "conv_wgrad: null pointer");
   SVAE_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(ws), SVAE_ERR_ALIGN,
                "conv_wgrad: pointers must be 16-byte aligned");
@@ -1140,6 +1153,8 @@ static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float*
   SVAE_REQUIRE(pieces > 0 || (wg.bm <= 128 && wg.bn <= 128), SVAE_ERR_SHAPE, "conv_wgrad: tile %dx%d exists for the split-bf16 kernel only",
                wg.bm, wg.bn);
   const int wvariant = d->tile[2] / 1000000;
+  SVAE_REQUIRE(!d->up2 || (pieces > 0 && (wvariant & 4)), SVAE_ERR_SHAPE,
+               "conv_wgrad: the fused x2 upsample of x exists in the all-taps split kernels only (tile codes 4 / 6 / 12 / 14 BBBNNN)");
   if (pieces > 0 && (wvariant & 4)) {
     const int Ls = d->transposed ? d->l_out : d->l_in;
     // Ls = nj stride + e: e = 0 contiguous convs, +1 the (k+1)-tap skip convs (2L -> 2L - 1), -1 odd-length stride-2 (transposed) convs.
@@ -1156,7 +1171,8 @@ static int conv_wgrad_impl(const svae_conv_desc* d, const float* x, const float*
                  "(e = %d, %d of %d rows)", e_rows, srows, sr_alloc);
     WgradTapsArgs a;
     memset(&a, 0, sizeof(a));
-    a.e = e_rows; a.srows = srows;
+    a.e = e_rows; a.srows = srows; a.up = d->up2;
+    if (d->up2) a.up_inv = ((1u << 20) + (unsigned)Ls - 1) / (unsigned)Ls;
     a.S = d->transposed ? dy : x; a.F = d->transposed ? x : dy;
     a.R = wg.R; a.rows_per_split = wg.rps; a.nj = wg.nj;
     a.Ls = Ls; a.ss = d->stride; a.dil = d->dilation; a.pad = d->padding; a.T = d->kernel;
@@ -1253,7 +1269,8 @@ extern "C" int svae_conv_tile(const svae_conv_desc* d, int kind, int* bm, int* b
   if (int e = validate(d)) return e;
   SVAE_REQUIRE(bm && bn && kind >= 0 && kind <= 2, SVAE_ERR_ARG, "conv_tile: bad args");
   if (kind == 2) {
-    const WgradGeo wg = wgrad_geometry(d);
+    const svae_conv_desc de = wgrad_desc(d);
+    const WgradGeo wg = wgrad_geometry(&de);
     *bm = wg.fused ? -wg.tg : wg.bm;  // negative: tap-fused kernel with TG = -bm
     *bn = wg.bn;
     return SVAE_OK;

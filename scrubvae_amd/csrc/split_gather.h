@@ -14,6 +14,7 @@ struct SplitGatherArgs {
   long long w_piece_stride;   // elements between piece planes
   long long rowsA;            // rows of the gathered operand (batch * Lin): bound of the halo image
   int KB;                     // 32-deep k blocks per tap
+  float* up_out;              // g.up: where the upsampled operand rows go as a by-product ([rowsA][ldA], NULL: nowhere)
 };
 
 // ---- epilogue shared by the gather kernels: C (+)= acc + bias, and -- when g.stats != NULL -- the BatchNorm batch statistics of

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC > 4 ? 1 : 2)) void wgrad_gem
 // Wave tile 32 (m) x WN (n) x T taps: T x NT accumulators of 32 x 32 (T = 5, NT = 2: 160 VGPRs).
 // LDS images: 64-byte chunks (32 channels) of a row XOR-swizzled by the row so that the 4 rows x 64 bytes a half-wave's transposing
 // read touches lie on different banks.
-template <int BM, int BN, int TMAX, int SS, bool TRANS_OUT>
+template <int BM, int BN, int TMAX, int SS, bool TRANS_OUT, bool UP = false>
 __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsArgs g) {
   constexpr int P = 2, KS = 32, NTH = 512;
   constexpr int WR = BM / 32, WC = 8 / WR, WN = BN / WC, NT = WN / 32;
@@ -321,17 +321,37 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
   // written behind the second k-step), so that only one of them occupies registers at a time: with 5 taps x 2 column blocks the
   // accumulators alone take 160 of the 256 registers.
   float4 sv[S_ITEMS], fv[F_ITEMS];
+  float4 sv2[UP ? S_ITEMS : 1];  // UP: the second source row of every image row (see load_s)
   auto load_s = [&](int kt) {
     const long long rk = r_begin + (long long)kt * KS;
     long long srow0 = rk * g.ss - g.pad;
     if (g.e != 0) srow0 += (rk / g.nj) * g.e;  // samples are Ls = nj ss + e rows apart: the image starts at the stage's first sample offset
+    unsigned up_q0 = 0, up_r0 = 0;  // UP: srow0 = (up_q0 - 1) Ls + up_r0, 0 <= up_r0 < Ls (srow0 >= -pad > -Ls)
+    if constexpr (UP) {
+      const unsigned t0 = (unsigned)(srow0 + g.Ls);
+      up_q0 = t0 / (unsigned)g.Ls;
+      up_r0 = t0 - up_q0 * (unsigned)g.Ls;
+    }
 #pragma unroll
     for (int i = 0; i < S_ITEMS; ++i) {
       const int idx = tid + NTH * i, row = idx / (BM / 4), cq = idx % (BM / 4);
       const long long sr = srow0 + row;
       // (select on the POINTER: a conditional load costs an exec-mask branch and a vmcnt(0) in front of the matrix work)
       const bool ok = (row < g.srows) & (sr >= 0) & (sr < g.rowsS) & (c0 + cq * 4 < g.Cs);  // srows = SR + the rows e > 0 adds (<= SR_ALLOC, host-checked)
-      sv[i] = *reinterpret_cast<const float4*>(ok ? g.S + sr * g.ldS + c0 + cq * 4 : wgrad_zero_row);
+      if constexpr (UP) {
+        // S is the x2 linear upsample (align_corners = false; reference residual.py:160) of the half-length tensor g.S points to:
+        // row (b, ro) of it = 0.75 x[b, ro / 2] + 0.25 x[b, ro / 2 -/+ 1] (clamped at the sample's ends), blended in store_s.
+        // (sample, position) of image row `row`: one wave-uniform division per stage (up_q0 / up_r0 above), then a multiply-shift
+        // per item -- per-item divisions made the staging VALU work the kernel's bottleneck (+30 %)
+        const unsigned rl = up_r0 + (unsigned)row, wq = (rl * g.up_inv) >> 20;  // exact: rl * Ls < 2^20 (host-checked)
+        const int ro = (int)(rl - wq * (unsigned)g.Ls), L = g.Ls >> 1, ii = ro >> 1;
+        const int i2 = (ro & 1) ? (ii + 1 < L ? ii + 1 : L - 1) : (ii > 0 ? ii - 1 : 0);
+        const float* base = g.S + ((long long)up_q0 - 1 + wq) * L * g.ldS + c0 + cq * 4;
+        sv[i] = *reinterpret_cast<const float4*>(ok ? base + (long long)ii * g.ldS : wgrad_zero_row);
+        sv2[i] = *reinterpret_cast<const float4*>(ok ? base + (long long)i2 * g.ldS : wgrad_zero_row);
+      } else {
+        sv[i] = *reinterpret_cast<const float4*>(ok ? g.S + sr * g.ldS + c0 + cq * 4 : wgrad_zero_row);
+      }
     }
   };
   auto load_f = [&](int kt) {
@@ -350,7 +370,12 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
     for (int i = 0; i < S_ITEMS; ++i) {
       const int idx = tid + NTH * i, row = idx / (BM / 4), cq = idx % (BM / 4);
       uint2 pc[P];
-      split4<P>(sv[i], pc);
+      if constexpr (UP) {
+        const float4 p = sv[i], q = sv2[i];
+        split4<P>(make_float4(0.75f * p.x + 0.25f * q.x, 0.75f * p.y + 0.25f * q.y, 0.75f * p.z + 0.25f * q.z, 0.75f * p.w + 0.25f * q.w), pc);
+      } else {
+        split4<P>(sv[i], pc);
+      }
 #pragma unroll
       for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(st + row * RSS + p * (BM * 2) + cq * 8) = pc[p];
     }
@@ -514,7 +539,7 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
 // lane group g = lane / 16 (k chunk 8 g ..), read j, row q of the transposing read's block  ->  stage row 16 j + 4 g + q, so that a
 // half-wave's read covers 8 CONSECUTIVE rows x 32 bytes -- conflict-free with image rows 32 bytes (mod 256) apart.
 
-template <int BM, int BN, int TMAX, int SS, bool TRANS_OUT>
+template <int BM, int BN, int TMAX, int SS, bool TRANS_OUT, bool UP = false>
 __global__ __launch_bounds__(512) void wgrad_taps16_bf16s_kernel(const WgradTapsArgs g) {
   constexpr int P = 2, KS = 32, NTH = 512, T = TMAX;
   constexpr int WR = BM / 32, WC = 8 / WR, WN = BN / WC, MB = 2, NB = WN / 16;
@@ -551,16 +576,36 @@ __global__ __launch_bounds__(512) void wgrad_taps16_bf16s_kernel(const WgradTaps
   for (int i = tid; i < ZBYTES / 4; i += NTH) reinterpret_cast<unsigned*>(smem + ZOFF)[i] = 0u;
 
   float4 sv[S_ITEMS], fv[F_ITEMS];
+  float4 sv2[UP ? S_ITEMS : 1];  // UP: the second source row of every image row (see load_s)
   auto load_s = [&](int kt) {
     const long long rk = r_begin + (long long)kt * KS;
     long long srow0 = rk * g.ss - g.pad;
     if (g.e != 0) srow0 += (rk / g.nj) * g.e;  // samples are Ls = nj ss + e rows apart: the image starts at the stage's first sample offset
+    unsigned up_q0 = 0, up_r0 = 0;  // UP: srow0 = (up_q0 - 1) Ls + up_r0, 0 <= up_r0 < Ls (srow0 >= -pad > -Ls)
+    if constexpr (UP) {
+      const unsigned t0 = (unsigned)(srow0 + g.Ls);
+      up_q0 = t0 / (unsigned)g.Ls;
+      up_r0 = t0 - up_q0 * (unsigned)g.Ls;
+    }
 #pragma unroll
     for (int i = 0; i < S_ITEMS; ++i) {
       const int idx = tid + NTH * i, row = idx / (BM / 4), cq = idx % (BM / 4);
       const long long sr = srow0 + row;
       const bool ok = (row < g.srows) & (sr >= 0) & (sr < g.rowsS) & (c0 + cq * 4 < g.Cs);  // srows = SR + the rows e > 0 adds (<= SR_ALLOC, host-checked)
-      sv[i] = *reinterpret_cast<const float4*>(ok ? g.S + sr * g.ldS + c0 + cq * 4 : wgrad_zero_row);
+      if constexpr (UP) {
+        // S is the x2 linear upsample (align_corners = false; reference residual.py:160) of the half-length tensor g.S points to:
+        // row (b, ro) of it = 0.75 x[b, ro / 2] + 0.25 x[b, ro / 2 -/+ 1] (clamped at the sample's ends), blended in store_s.
+        // (sample, position) of image row `row`: one wave-uniform division per stage (up_q0 / up_r0 above), then a multiply-shift
+        // per item -- per-item divisions made the staging VALU work the kernel's bottleneck (+30 %)
+        const unsigned rl = up_r0 + (unsigned)row, wq = (rl * g.up_inv) >> 20;  // exact: rl * Ls < 2^20 (host-checked)
+        const int ro = (int)(rl - wq * (unsigned)g.Ls), L = g.Ls >> 1, ii = ro >> 1;
+        const int i2 = (ro & 1) ? (ii + 1 < L ? ii + 1 : L - 1) : (ii > 0 ? ii - 1 : 0);
+        const float* base = g.S + ((long long)up_q0 - 1 + wq) * L * g.ldS + c0 + cq * 4;
+        sv[i] = *reinterpret_cast<const float4*>(ok ? base + (long long)ii * g.ldS : wgrad_zero_row);
+        sv2[i] = *reinterpret_cast<const float4*>(ok ? base + (long long)i2 * g.ldS : wgrad_zero_row);
+      } else {
+        sv[i] = *reinterpret_cast<const float4*>(ok ? g.S + sr * g.ldS + c0 + cq * 4 : wgrad_zero_row);
+      }
     }
   };
   auto load_f = [&](int kt) {
@@ -579,7 +624,12 @@ __global__ __launch_bounds__(512) void wgrad_taps16_bf16s_kernel(const WgradTaps
     for (int i = 0; i < S_ITEMS; ++i) {
       const int idx = tid + NTH * i, row = idx / (BM / 4), cq = idx % (BM / 4);
       uint2 pc[P];
-      split4<P>(sv[i], pc);
+      if constexpr (UP) {
+        const float4 p = sv[i], q = sv2[i];
+        split4<P>(make_float4(0.75f * p.x + 0.25f * q.x, 0.75f * p.y + 0.25f * q.y, 0.75f * p.z + 0.25f * q.z, 0.75f * p.w + 0.25f * q.w), pc);
+      } else {
+        split4<P>(sv[i], pc);
+      }
 #pragma unroll
       for (int p = 0; p < P; ++p) *reinterpret_cast<uint2*>(st + row * RSS + p * (BM * 2) + cq * 8) = pc[p];
     }
@@ -727,6 +777,19 @@ int launch_wgrad_taps(const WgradTapsArgs& g, dim3 grid, hipStream_t st, int bm,
       else hipLaunchKernelGGL((wgrad_taps_bf16s_kernel<BM_, BN_, T_, S_, false>), grid, block, 0, st, g);                 \
     } } while (0)
   if (g.dil != 1 || (g.ss != 1 && g.ss != 2) || (g.T != 5 && g.T != 6)) { set_error("wgrad taps: built for 5 or 6 taps, stride 1 or 2, dilation 1"); return SVAE_ERR_SHAPE; }
+  if (g.up) {  // the shifted operand is the x2 linear upsample of g.S, blended while it is staged: the (k+1)-tap skip convs of the decoder
+    if (g.T != 6 || g.ss != 1 || trans_out || (g.Ls & 1) || g.Ls > 512 || g.pad >= g.Ls || g.rowsS >= 0x7fffffffLL || g.up_inv != ((1u << 20) + g.Ls - 1) / g.Ls ||
+        !((bm == 64 && bn == 128) || (bm == 128 && bn == 64))) {
+      set_error("wgrad taps: the fused upsample exists for 6-tap stride-1 convs on 64x128 / 128x64 tiles");
+      return SVAE_ERR_SHAPE;
+    }
+#define SVAE_WTU(BM_, BN_) do {                                                                                            \
+    if (m16) hipLaunchKernelGGL((wgrad_taps16_bf16s_kernel<BM_, BN_, 6, 1, false, true>), grid, block, 0, st, g);          \
+    else hipLaunchKernelGGL((wgrad_taps_bf16s_kernel<BM_, BN_, 6, 1, false, true>), grid, block, 0, st, g); } while (0)
+    if (bm == 64) SVAE_WTU(64, 128); else SVAE_WTU(128, 64);
+#undef SVAE_WTU
+    return check_launch("wgrad_taps_bf16s<up>");
+  }
 #define SVAE_WTT(BM_, BN_, S_) do { if (g.T == 5) SVAE_WT(BM_, BN_, 5, S_); else SVAE_WT(BM_, BN_, 6, S_); } while (0)
   if (bm == 128 && bn == 128 && g.T == 5) { if (g.ss == 1) SVAE_WT(128, 128, 5, 1); else SVAE_WT(128, 128, 5, 2); }
   else if (bm == 64 && bn == 128) { if (g.ss == 1) SVAE_WTT(64, 128, 1); else SVAE_WTT(64, 128, 2); }

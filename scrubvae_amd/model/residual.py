@@ -52,6 +52,9 @@ def find_out_dim(latent_dim, kernel, num_layers, dilation=None):
 
 
 _APPLY_COLSUM = os.environ.get("SVAE_APPLY_COLSUM", "1") != "0"  # env: experiments (0 = bias gradients by a separate pass over dY)
+# env: A/B measurements ("0": upsample2_fwd always writes the `up` tensor the skip convs read; "force": fused wherever the kernels
+# exist, tuned on first use; default: fused where the tile table says so)
+FUSE_UPSAMPLE = os.environ.get("SVAE_FUSE_UPSAMPLE", "1")
 _SIDE_STREAMS = {}  # device index -> side streams shared by every model of the process (see ResVAE._side_stream)
 
 
@@ -394,11 +397,18 @@ class ResVAE(nn.Module):
             self._ws[key] = t
         return t
 
-    def _conv(self, name, p: ConvP, batch, l_in, ld_in=None, ld_out=None):
+    def _conv(self, name, p: ConvP, batch, l_in, ld_in=None, ld_out=None, up2=False):
         key = (name, batch, l_in, ld_in, ld_out)
         c = self._convs.get(key)
         if c is None:
             c = ops.Conv(batch, l_in, p.c_in, p.c_out, p.kernel, p.stride, p.padding, p.dilation, p.transposed, ld_in, ld_out)
+            if up2 and FUSE_UPSAMPLE != "0" and c.pieces and ops.up2_supported(p.kernel, p.stride, p.dilation, p.transposed):
+                # the conv behind the decoder's Upsample(x2): its forward can blend the half-length input on the fly.  It does where
+                # that was MEASURED to pay -- the geometry has an ":up2" entry in the tile table (large batches: the fused kernel
+                # fetches half the operand rows; at small ones the upsample pass is cheap and the kernel choice narrower)
+                cu = ops.Conv(batch, l_in, p.c_in, p.c_out, p.kernel, p.stride, p.padding, p.dilation, p.transposed, ld_in, ld_out, up2=True)
+                if FUSE_UPSAMPLE == "force" or cu.tile_key("fwd") in ops.TILE_TABLE:
+                    c = cu
             self._convs[key] = c
             if c.pieces:
                 self._split_users[key] = (c, p)
@@ -859,15 +869,19 @@ class ResVAE(nn.Module):
             cv2 = self._conv(t + ".t2", ct2, B, L)
             Lo = cv2.l_out
             s = self._buf(t + ".s", (B * Lo, cv2.c_out_p))
-            up = self._buf(t + ".up", (B * 2 * L, cv1.c_in_p))
             sk = blk.skip[1]
-            cvs = self._conv(t + ".sk", sk, B, 2 * L)
+            cvs = self._conv(t + ".sk", sk, B, 2 * L, up2=True)
             if cvs.l_out != Lo:
                 raise ValueError("skip / residual length mismatch")
+            keep_up = self.training and not (cvs.up2 and cvs.up2_wgrad)  # the weight gradient's operand
+            up = self._buf(t + ".up", (B * 2 * L, cv1.c_in_p)) if (keep_up or not cvs.up2) else None
 
             def skip_branch(d=d, up=up, cvs=cvs, sk=sk, s=s, L=L, cin=cv1.c_in_p):
-                ops.upsample2_fwd(d, up, B, L, cin, cin)
-                cvs.fwd(up, sk.weight, sk.bias, s)
+                if cvs.up2:  # Upsample(x2, linear) folded into the conv's operand staging; `up` is a by-product (training only)
+                    cvs.fwd(d, sk.weight, sk.bias, s, up_out=up)
+                else:
+                    ops.upsample2_fwd(d, up, B, L, cin, cin)
+                    cvs.fwd(up, sk.weight, sk.bias, s)
 
             self._fork(skip_branch)  # upsample + skip conv on the side stream
             t0 = self._buf(t + ".t0", (B * L, cv1.c_out_p))
@@ -1163,14 +1177,13 @@ class ResVAE(nn.Module):
             sk = blk.skip[1]
             cv1 = self._conv(t + ".t1", ct1, B, L)
             cv2 = self._conv(t + ".t2", ct2, B, L)
-            cvs = self._conv(t + ".sk", sk, B, 2 * L)
+            cvs = self._conv(t + ".sk", sk, B, 2 * L, up2=True)
             d_in = self._buf(f"dec.{j - 1}.a", (B * L, cv1.c_in_p)) if j > 0 else self._buf("dec.f", (B, L * cv1.c_in_p)).view(B * L, cv1.c_in_p)
             s = self._buf(t + ".s", (B * Lo, cv2.c_out_p))
             g_s = self._buf("g." + t + ".s", (B * Lo, cv2.c_out_p))
             self._bn_act_bwd(t + ".bn2", g, s, blk.add[0], blk.add[1], B * Lo, g_s, acc, fz.get(t + ".bn2"))
-            up = self._buf(t + ".up", (B * 2 * L, cv1.c_in_p))
             t0a = self._buf(t + ".t0a", (B * L, cv1.c_out_p))
-            self._wgrad(cvs, up, g_s, sk, acc)
+            self._wgrad(cvs, d_in if (cvs.up2 and cvs.up2_wgrad) else self._buf(t + ".up", (B * 2 * L, cv1.c_in_p)), g_s, sk, acc)
             self._wgrad(cv2, t0a, g_s, ct2, acc)
             g_up = self._buf("g." + t + ".up", (B * 2 * L, cv1.c_in_p))
             g_d = self._buf("g." + t + ".in", (B * L, cv1.c_in_p))

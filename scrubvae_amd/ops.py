@@ -178,6 +178,11 @@ MIX_F32 = True  # a bf16x6 conv may keep the fp32 MFMA kernel for a pass where t
 WEIGHT_EPOCH = 0  # bumped whenever master weights may have changed (start of every model pass)
 
 
+def up2_supported(kernel, stride=1, dilation=1, transposed=False):
+    """Geometries whose forward and weight-gradient kernels can take the x2 linear upsample of their input on the fly."""
+    return kernel == 6 and stride == 1 and dilation == 1 and not transposed
+
+
 def set_precision(name):
     global PRECISION
     if name not in _PIECES:
@@ -230,7 +235,11 @@ class Conv:
     """Geometry of one nn.Conv1d / nn.ConvTranspose1d / nn.Linear call (padded channels)."""
 
     def __init__(self, batch, l_in, c_in, c_out, kernel, stride=1, padding=0, dilation=1, transposed=False,
-                 ld_in=None, ld_out=None, pieces=None):
+                 ld_in=None, ld_out=None, pieces=None, up2=False):
+        """up2: the conv's input is the x2 linear upsample of a [batch * l_in / 2, c_in] tensor (l_in: the upsampled length): `fwd`
+        takes that half-length tensor, its kernel blends the rows while staging them (svae_conv_desc.up2) and can leave the upsampled
+        tensor behind as a by-product (`up_out`) for `wgrad`, which reads it like any conv (or, with `up2_wgrad`, blends the half-length
+        tensor too); `dgrad` returns the gradient with respect to the upsampled input.  Split-precision convs only (`up2_supported`)."""
         self.c_in, self.c_out = c_in, c_out
         self.c_in_p, self.c_out_p = pad16(c_in), pad16(c_out)
         if transposed:
@@ -242,6 +251,10 @@ class Conv:
         self.desc = ConvDesc(batch, l_in, l_out, self.c_in_p, self.c_out_p,
                              ld_in or self.c_in_p, ld_out or self.c_out_p,
                              kernel, stride, padding, dilation, 1 if transposed else 0)
+        self.up2 = bool(up2)
+        # up2_wgrad: the weight gradient blends the half-length input too (all-taps kernels; measured 30 % slower than the plain
+        # kernels on the upsampled tensor -- twice the operand requests -- so the default reads the forward's `up_out` by-product)
+        self.up2_wgrad = False
         self._ws_bytes = None
         # algorithmic FLOPs of one pass (forward = dgrad = wgrad): 2*B*L*k*Cin*Cout with the
         # unpadded channel counts, L = output length (conv) / input length (transposed conv)
@@ -252,6 +265,14 @@ class Conv:
         self.wgrad_pieces = (_WGRAD_PIECES.get(PRECISION, self.pieces) if self.pieces else 0) if pieces is None else int(pieces)
         self.dgrad_pieces = (_DGRAD_PIECES.get(PRECISION, self.pieces) if self.pieces else 0) if pieces is None else int(pieces)
         self._wsplit, self._split_epoch, self._split_src = None, -1, None
+        if up2 and not (self.pieces and up2_supported(kernel, stride, dilation, transposed)):
+            raise ValueError("Conv(up2=True): the fused upsample exists for split-precision 6-tap stride-1 nn.Conv1d geometries")
+
+    def _dref(self, kind):
+        """The descriptor as pass `kind` sees it: svae_conv_desc.up2 is set for the forward of an up2 conv (and for its weight
+        gradient with up2_wgrad); the other passes run the plain geometry on full-length tensors."""
+        self.desc.up2 = 1 if (self.up2 and (kind == "fwd" or (kind == "wgrad" and self.up2_wgrad))) else 0
+        return C.byref(self.desc)
 
     def split_weights(self, w):
         """bf16 piece planes of `w` for the split kernels; re-split once per weight epoch."""
@@ -279,6 +300,15 @@ class Conv:
         self.__dict__.pop("_stats_tiles", None)
         self.__dict__.pop("_dstats_tiles", None)
 
+    def tile_key(self, kind):
+        """Key of this geometry's pass `kind` in the tile table (tuned_tiles.json / TUNED_LOG)."""
+        d = self.desc
+        base = self._base_pieces(kind)
+        key = f"{kind}{'@' + str(base) if base else ''}:{d.batch}:{d.l_in}:{d.c_in}:{d.c_out}:{d.ld_in}:{d.ld_out}:{d.kernel}:{d.stride}:{d.padding}:{d.transposed}"
+        if self.up2 and (kind == "fwd" or (kind == "wgrad" and self.up2_wgrad)):  # the other passes share the plain geometry's entries
+            key += ":up2"
+        return key
+
     def _tune(self, kind, run):
         """run(): launches this conv once with scratch outputs.  Picks the kernel family (for a
         bf16x6 conv: split-bf16 or fp32 MFMA -- both are fp32-accurate) and desc.tile[kind]."""
@@ -293,9 +323,8 @@ class Conv:
                 return self._tune(kind, run)
             finally:
                 _TLS.stream_override = keep
-        d = self.desc
         base = self._base_pieces(kind)
-        key = f"{kind}{'@' + str(base) if base else ''}:{d.batch}:{d.l_in}:{d.c_in}:{d.c_out}:{d.ld_in}:{d.ld_out}:{d.kernel}:{d.stride}:{d.padding}:{d.transposed}"
+        key = self.tile_key(kind)
         if key in TILE_TABLE:
             v = int(TILE_TABLE[key])
             self._set_choice(kind, 0 if v >= self._F32_FLAG else base, v % self._F32_FLAG)
@@ -334,24 +363,26 @@ class Conv:
         names = self.__dict__.setdefault("_names", {})
         if kind not in names:
             bm, bn = C.c_int(), C.c_int()
-            check(_lib.lib().svae_conv_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn)), "conv_tile")
+            check(_lib.lib().svae_conv_tile(self._dref(kind), _KIND_ID[kind], C.byref(bm), C.byref(bn)), "conv_tile")
             kp = self._kind_pieces(kind)
             P, H = (2, "true") if kp == F16X2 else (kp, "false")
-            if kp and kind == "wgrad" and (self.desc.tile[2] // 1000000) & 4:
-                names[kind] = (f"wgrad_taps{'16' if (self.desc.tile[2] // 1000000) & 8 else ''}_bf16s_kernel<{bm.value}, {bn.value}, {self.kernel}, "
-                               f"{self.desc.stride}, {'true' if self.desc.transposed else 'false'}>")
+            wcode = self.desc.tile[2] or (4064128 if (self.up2 and self.up2_wgrad) else 0)  # the library's default for up2 convs: the all-taps kernel
+            if kp and kind == "wgrad" and (wcode // 1000000) & 4:
+                names[kind] = (f"wgrad_taps{'16' if (wcode // 1000000) & 8 else ''}_bf16s_kernel<{bm.value}, {bn.value}, {self.kernel}, "
+                               f"{self.desc.stride}, {'true' if self.desc.transposed else 'false'}, {'true' if (self.up2 and self.up2_wgrad) else 'false'}>")
             elif kp and kind == "wgrad":
                 waves = {256256: "2, 4", 256128: "4, 2", 128256: "2, 4"}.get(self.desc.tile[2] % 1000000, "2, 2")
                 names[kind] = f"wgrad_gemm_bf16s_kernel<{bm.value}, {bn.value}, {kp}, {1 if (self.desc.tile[2] // 1000000) & 1 else 2}, {waves}>"
             elif kp:
                 v, rm = C.c_int(), C.c_int()
-                check(_lib.lib().svae_conv_split_tile(C.byref(self.desc), _KIND_ID[kind], C.byref(bm), C.byref(bn), C.byref(v),
+                check(_lib.lib().svae_conv_split_tile(self._dref(kind), _KIND_ID[kind], C.byref(bm), C.byref(bn), C.byref(v),
                                                       C.byref(rm)), "conv_split_tile")
                 v = v.value
                 if v in (8, 9):
-                    names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {rm.value}, {H}>"
+                    up = "true" if (self.up2 and kind == "fwd") else "false"
+                    names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {320 if (up == 'true' and v == 9) else rm.value}, {H}, {up}>"
                 elif v == 19:
-                    names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {P}, 8, 1, {rm.value}, {H}>"
+                    names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {P}, 8, 1, {rm.value}, {H}, false>"
                 elif v in (10, 11, 12, 13):
                     names[kind] = f"gather_halo_ws_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {rm.value}, 0, false, {3 if v >= 12 else 2}, {H}>"
                 elif v in (16, 17):
@@ -384,11 +415,11 @@ class Conv:
             keep, need = self.desc.tile[2], 0
             for code in (_SPLIT_WGRAD_CODES if self._base_pieces("wgrad") else _WGRAD_CODES):
                 self.desc.tile[2] = code
-                need = max(need, int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc))))
+                need = max(need, int(_lib.lib().svae_conv_wgrad_workspace(self._dref("wgrad"))))
             self.desc.tile[2] = keep
             return need
         if self._ws_bytes is None:
-            self._ws_bytes = int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc)))
+            self._ws_bytes = int(_lib.lib().svae_conv_wgrad_workspace(self._dref("wgrad")))
         return self._ws_bytes
 
     def _splitk_ws(self, kind_id, device):
@@ -408,21 +439,26 @@ class Conv:
             return 0
         n = self.__dict__.get("_stats_tiles")
         if n is None:
-            n = self.__dict__["_stats_tiles"] = int(_lib.lib().svae_conv_fwd_stats_tiles(C.byref(self.desc)))
+            n = self.__dict__["_stats_tiles"] = int(_lib.lib().svae_conv_fwd_stats_tiles(self._dref("fwd")))
         return n
 
-    def _launch_fwd(self, x, w, bias, y, acc, stats=None):
+    def _launch_fwd(self, x, w, bias, y, acc, stats=None, up_out=None):
         kp = self._kind_pieces("fwd")
+        if kp and self.up2:
+            return check(_lib.lib().svae_conv_fwd_split_up2(self._dref("fwd"), _p(x), _p(self.split_weights(w)), _p(bias), _p(y),
+                                                             acc, kp, _p(stats), _p(up_out), _stream()), "conv_fwd_split_up2")
+        if up_out is not None:
+            raise RuntimeError("conv_fwd: up_out is the by-product of an up2 conv's split-precision forward")
         if kp:
-            return check(_lib.lib().svae_conv_fwd_split_stats(C.byref(self.desc), _p(x), _p(self.split_weights(w)), _p(bias), _p(y),
+            return check(_lib.lib().svae_conv_fwd_split_stats(self._dref("fwd"), _p(x), _p(self.split_weights(w)), _p(bias), _p(y),
                                                                acc, kp, _p(stats), _stream()), "conv_fwd_split")
         if stats is not None:
             raise RuntimeError("conv_fwd: fused BatchNorm statistics need a split-bf16 forward kernel (check stats_tiles())")
         ws = self._splitk_ws(0, x.device)
         if ws is not None:
-            return check(_lib.lib().svae_conv_fwd_ws(C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), acc, _p(ws), ws.numel() * 4,
+            return check(_lib.lib().svae_conv_fwd_ws(self._dref("fwd"), _p(x), _p(w), _p(bias), _p(y), acc, _p(ws), ws.numel() * 4,
                                                      _stream()), "conv_fwd_ws")
-        return check(_lib.lib().svae_conv_fwd(C.byref(self.desc), _p(x), _p(w), _p(bias), _p(y), acc, _stream()), "conv_fwd")
+        return check(_lib.lib().svae_conv_fwd(self._dref("fwd"), _p(x), _p(w), _p(bias), _p(y), acc, _stream()), "conv_fwd")
 
     def dgrad_stats_tiles(self):
         """(row tiles, column blocks) of the data-gradient launch when its kernel can emit the sums of a BatchNorm + activation
@@ -453,9 +489,9 @@ class Conv:
         nbytes = ws.numel() * ws.element_size()
         kp = self._kind_pieces("wgrad")
         if kp:
-            return check(_lib.lib().svae_conv_wgrad_split(C.byref(self.desc), _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes,
+            return check(_lib.lib().svae_conv_wgrad_split(self._dref("wgrad"), _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes,
                                                            acc, kp, _stream()), "conv_wgrad_split")
-        return check(_lib.lib().svae_conv_wgrad(C.byref(self.desc), _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, acc,
+        return check(_lib.lib().svae_conv_wgrad(self._dref("wgrad"), _p(x), _p(dy), _p(dw), _p(db), _p(ws), nbytes, acc,
                                                  _stream()), "conv_wgrad")
 
     def tune_fwd(self, x, w, bias):
@@ -464,10 +500,11 @@ class Conv:
             scratch = torch.empty(self.batch * self.l_out * self.desc.ld_out + 16, device=x.device)
             self._tune("fwd", lambda: self._launch_fwd(x, w, bias, scratch, 0))
 
-    def fwd(self, x, w, bias, y, accumulate=False, stats=None):
-        """stats: [stats_tiles()][2][c_out_p] buffer for the fused BatchNorm statistics of y (None: off)"""
+    def fwd(self, x, w, bias, y, accumulate=False, stats=None, up_out=None):
+        """stats: [stats_tiles()][2][c_out_p] buffer for the fused BatchNorm statistics of y (None: off);
+        up_out (up2 convs): [batch * l_in, c_in_p] buffer that receives the upsampled input rows as a by-product (None: off)"""
         self.tune_fwd(x, w, bias)
-        _timed("fwd", self, self.c_out_p, lambda: self._launch_fwd(x, w, bias, y, int(accumulate), stats))
+        _timed("fwd", self, self.c_out_p, lambda: self._launch_fwd(x, w, bias, y, int(accumulate), stats, up_out))
         return y
 
     def tune_dgrad(self, dy, w):
@@ -490,7 +527,7 @@ class Conv:
             need = 0
             for code in (_SPLIT_WGRAD_CODES if self._base_pieces("wgrad") else _WGRAD_CODES):  # scratch workspace large enough for every candidate
                 self.desc.tile[2] = code
-                need = max(need, int(_lib.lib().svae_conv_wgrad_workspace(C.byref(self.desc))))
+                need = max(need, int(_lib.lib().svae_conv_wgrad_workspace(self._dref("wgrad"))))
             self.desc.tile[2] = 0
             sws = torch.empty(need // 4 + 16, device=x.device)
             self._tune("wgrad", lambda: self._launch_wgrad(x, dy, sdw, sdb, sws, 0))

@@ -39,7 +39,9 @@ WIDE6 = (64, 128, 256, 512, 1024, 2048, 4096)  # BASELINE configs[4]: six residu
 
 
 def _run(B, full, precision, seed, window=64, channel=None, expect=("gather_halo_bf16s_kernel", "gather_halo_ws4", "wgrad_taps"),
-         out_tol=2e-5):
+         out_tol=2e-5, report=None):
+    """report: a list -- per-tensor (name, numel, error vs fp64, fp32 oracle's error vs fp64) instead of the per-tensor gates
+    (tools/fullsize_slopes.py)"""
     from scrubvae_amd import ops
     from scrubvae_amd.train.losses import get_batch_loss
     from scrubvae_amd.train.trainer import FusedAdam, clip_grad_norm_
@@ -111,6 +113,9 @@ def _run(B, full, precision, seed, window=64, channel=None, expect=("gather_halo
         #  noise of the fp32-class inputs, as in the oracle: 4.4e-2 (f16x3b3) / 5.9e-2 (bf16x6b3, and the same with six products in
         #  the backward pass) at B=1024, 8e-3 at B=4096; no special case for them)
         gate = max(5e-2, 4 * e_cpu)
+        if report is not None:
+            report.append((n, t.numel(), e_hip, e_cpu))
+            continue
         assert e_hip < gate, (n, e_hip, e_cpu)
         assert e_pair < gate + e_cpu, (n, e_pair, e_cpu)
     nrm = lambda ts: torch.sqrt(sum((x.double() ** 2).sum() for x in ts))

@@ -684,6 +684,102 @@ def test_split_wgrad_kernels(ops, case, code, pieces):
     assert relerr(ops.conv_weight_from_tio(dwd.cpu(), Cin, Cout, tr), 2 * w.grad) < bound
 
 
+@pytest.mark.parametrize("geo", [(3, 4, 48, 40), (5, 7, 32, 64), (2, 25, 16, 32), (64, 13, 128, 64), (300, 4, 64, 128)])
+@pytest.mark.parametrize("fcode,pieces", [(8128128, 22), (8128064, 3), (9128128, 22), (9128064, 2), (9128128, 3), (0, 22)])
+@pytest.mark.parametrize("wcode", [4064128, 6128064, 12064128, 14128064, 0])
+def test_conv_behind_upsample_fused(ops, geo, fcode, pieces, wcode):
+    """nn.Upsample(scale_factor=2, mode="linear") -> nn.Conv1d(k + 1 taps) of the decoder's skip path (reference residual.py:153-170)
+    with the upsample folded into the operand staging of the forward (halo kernels, tile codes 8 / 9) and of the all-taps weight
+    gradient (svae_conv_desc.up2): against torch fp64, and against the unfused launches (svae_upsample2_fwd + the same kernels), which
+    see the same blended fp32 values."""
+    B, L, Cin, Cout = geo
+    k, pad = 6, 2
+    g = torch.Generator().manual_seed(17 + sum(geo))
+    xh = torch.randn(B, Cin, L, generator=g, dtype=torch.float64)
+    w = (torch.randn(Cout, Cin, k, generator=g, dtype=torch.float64) / math.sqrt(Cin * k)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    up = F.interpolate(xh, scale_factor=2, mode="linear", align_corners=False)
+    y = F.conv1d(up, w, b, padding=pad)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    with pytest.raises(ValueError):
+        ops.Conv(B, 2 * L, Cin, Cout, 5, 1, 2, pieces=pieces, up2=True)  # 5 taps: not a geometry behind the upsampler
+    cvu = ops.Conv(B, 2 * L, Cin, Cout, k, 1, pad, pieces=pieces, up2=True)
+    cvp = ops.Conv(B, 2 * L, Cin, Cout, k, 1, pad, pieces=pieces)
+    cvu.up2_wgrad = True  # the fused weight gradient too (the model's default reads the forward's by-product instead)
+    for cv in (cvu, cvp):
+        cv.wgrad_pieces = cv.dgrad_pieces = 2
+        cv.__dict__["_tuned"] = {"fwd", "dgrad", "wgrad"}
+        cv.desc.tile[0] = fcode if (fcode or cv is cvu) else 8128128
+        cv.desc.tile[2] = wcode if (wcode or cv is cvu) else 4064128
+        cv._ws_bytes = None
+    ops.bump_weight_epoch()
+    wd = ops.conv_weight_to_tio(w.detach().float()).cuda().contiguous()
+    bd = torch.zeros(cvu.c_out_p); bd[:Cout] = b.float(); bd = bd.cuda()
+    xd = to_nlc(xh)
+    upd = torch.empty(B * 2 * L, cvu.c_in_p, device="cuda")
+    ops.upsample2_fwd(xd, upd, B, L, cvu.c_in_p, cvu.c_in_p)
+    yu = torch.full((B * cvu.l_out, cvu.c_out_p), float("nan"), device="cuda")
+    yp = torch.full_like(yu, float("nan"))
+    try:
+        cvu.fwd(xd, wd, bd, yu)
+    except RuntimeError as e:
+        if fcode // 1000000 == 9 and "does not fit" in str(e):
+            pytest.skip("256-row halo image larger than LDS for this geometry")
+        raise
+    cvp.fwd(upd, wd, bd, yp)
+    # by-product: the upsampled tensor itself, every row exactly once (NaN-filled before)
+    upo = torch.full_like(upd, float("nan"))
+    yo = torch.full_like(yu, float("nan"))
+    cvu.fwd(xd, wd, bd, yo, up_out=upo)
+    assert torch.equal(yo, yu) and torch.equal(upo, upd)
+    with pytest.raises(RuntimeError):
+        cvp.fwd(upd, wd, bd, yp, up_out=upo)
+    tol = _SPLIT_TOL[pieces]
+    assert relerr(from_nlc(yu, B, cvu.l_out, Cout), y.detach()) < tol * math.sqrt(Cin * k) + tol
+    assert relerr(yu, yp) < 1e-6  # the same blended values through the same kernel
+    assert "true>" in cvu.kernel_name("fwd") and "false>" in cvp.kernel_name("fwd")
+    # fused BatchNorm statistics and accumulate through the fused path as through the plain one
+    nt = cvu.stats_tiles()
+    part = torch.full((nt, 2, cvu.c_out_p), float("nan"), device="cuda")
+    cvu.fwd(xd, wd, bd, yu, accumulate=True, stats=part)
+    assert relerr(part.double().sum(0)[0], yu.double().sum(0)) < 1e-5 * math.sqrt(yu.shape[0])
+    # weight gradient
+    dyd = to_nlc(dy)
+    wsu = torch.empty(cvu.wgrad_workspace_bytes() // 4 + 4, device="cuda")
+    wsp = torch.empty(cvp.wgrad_workspace_bytes() // 4 + 4, device="cuda")
+    dwu = torch.full(cvu.weight_shape, float("nan"), device="cuda")
+    dwp = torch.full(cvu.weight_shape, float("nan"), device="cuda")
+    cvu.wgrad(xd, dyd, dwu, None, wsu)
+    cvp.wgrad(upd, dyd, dwp, None, wsp)
+    bound = _SPLIT_TOL[2] * math.sqrt(B * y.shape[-1]) + _SPLIT_TOL[2]
+    assert relerr(ops.conv_weight_from_tio(dwu.cpu(), Cin, Cout), w.grad) < bound
+    assert relerr(dwu, dwp) < 1e-6
+    cvu.wgrad(xd, dyd, dwu, None, wsu, accumulate=True)
+    assert relerr(ops.conv_weight_from_tio(dwu.cpu(), Cin, Cout), 2 * w.grad) < bound
+    # the data gradient is the plain geometry's (with respect to the upsampled input)
+    gu = torch.full((B * 2 * L, cvu.c_in_p), float("nan"), device="cuda")
+    cvu.dgrad(dyd, wd, gu)
+    upr = up.detach().requires_grad_(True)
+    F.conv1d(upr, w.detach(), b, padding=pad).backward(dy)
+    assert relerr(from_nlc(gu, B, 2 * L, Cin), upr.grad) < _SPLIT_TOL[2] * math.sqrt(Cout * k) + _SPLIT_TOL[2]
+    # kernels without the fused path refuse the flag instead of reading the half-length tensor as a full one
+    cvu.desc.tile[0] = 16128128
+    with pytest.raises(RuntimeError):
+        cvu.fwd(xd, wd, bd, yu)
+    cvu.desc.tile[0] = fcode
+    cvu.desc.tile[2] = 2128128
+    cvu._ws_bytes = None
+    with pytest.raises(RuntimeError):
+        cvu.wgrad(xd, dyd, dwu, None, torch.empty(cvu.wgrad_workspace_bytes() // 4 + 4, device="cuda"))
+    # ... while the plain weight gradient of the same Conv takes the full-length tensor on any kernel
+    cvu.up2_wgrad = False
+    cvu._ws_bytes = None
+    cvu.__dict__.pop("_names", None)
+    cvu.wgrad(upd, dyd, dwu, None, torch.empty(cvu.wgrad_workspace_bytes() // 4 + 4, device="cuda"))
+    assert relerr(ops.conv_weight_from_tio(dwu.cpu(), Cin, Cout), w.grad) < bound
+
+
 def test_split_weight_copies_follow_the_epoch(ops):
     """The bf16 weight pieces are refreshed when the weight epoch is bumped, not before."""
     cv = ops.Conv(4, 16, 32, 32, 5, 1, 2, pieces=3)
