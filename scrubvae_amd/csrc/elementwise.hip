@@ -450,8 +450,7 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float* __restr
       const int ii = ro >> 1;
       const int i2 = (ro & 1) ? (ii + 1 < L ? ii + 1 : L - 1) : (ii > 0 ? ii - 1 : 0);
       const float4 p = ld4(x + ((long long)b * L + ii) * ld + c), q = ld4(x + ((long long)b * L + i2) * ld + c);
-      st4(y + (long long)row * ld + c, make_float4(0.75f * p.x + 0.25f * q.x, 0.75f * p.y + 0.25f * q.y, 0.75f * p.z + 0.25f * q.z,
-                                                    0.75f * p.w + 0.25f * q.w));
+      st4(y + (long long)row * ld + c, up2_blend4(p, q));
     }
     return;
   }
@@ -463,8 +462,7 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float* __restr
     const int ii = ro >> 1;
     const int i2 = (ro & 1) ? (ii + 1 < L ? ii + 1 : L - 1) : (ii > 0 ? ii - 1 : 0);
     const float4 p = ld4(x + (b * L + ii) * ld + c), q = ld4(x + (b * L + i2) * ld + c);
-    st4(y + row * ld + c, make_float4(0.75f * p.x + 0.25f * q.x, 0.75f * p.y + 0.25f * q.y, 0.75f * p.z + 0.25f * q.z,
-                                      0.75f * p.w + 0.25f * q.w));
+    st4(y + row * ld + c, up2_blend4(p, q));
   }
 }
 

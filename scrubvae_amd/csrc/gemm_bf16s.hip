@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
       float4 v = ra[i];
       if constexpr (UP) {
         const float4 q = ra2[i];
-        v = make_float4(0.75f * v.x + 0.25f * q.x, 0.75f * v.y + 0.25f * q.y, 0.75f * v.z + 0.25f * q.z, 0.75f * v.w + 0.25f * q.w);
+        v = up2_blend4(v, q);
         // by-product: the upsampled rows this tile OWNS (first row's anchor up to the next tile's) go to sa.up_out -- the operand of the
         // conv's weight gradient in the backward pass -- from the first column tile only; halo rows belong to the neighbours
         if (up_store[i] && ra_ok[i]) *reinterpret_cast<float4*>(sa.up_out + (gbase + r) * (long long)g.ldA + st_c) = v;

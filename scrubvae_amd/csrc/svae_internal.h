@@ -50,6 +50,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// x2 linear upsample (align_corners = false): 0.75 near + 0.25 far, ONE rounding order everywhere it is evaluated (the standalone
+// kernel, the kernels that blend while staging an operand, the by-product they leave for the weight gradient): bit-identical rows
+__device__ __forceinline__ float up2_blend(float near_, float far_) { return __builtin_fmaf(0.25f, far_, 0.75f * near_); }
+__device__ __forceinline__ float4 up2_blend4(float4 p, float4 q) {
+  return make_float4(up2_blend(p.x, q.x), up2_blend(p.y, q.y), up2_blend(p.z, q.z), up2_blend(p.w, q.w));
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(512) void wgrad_taps_bf16s_kernel(const WgradTapsAr
       uint2 pc[P];
       if constexpr (UP) {
         const float4 p = sv[i], q = sv2[i];
-        split4<P>(make_float4(0.75f * p.x + 0.25f * q.x, 0.75f * p.y + 0.25f * q.y, 0.75f * p.z + 0.25f * q.z, 0.75f * p.w + 0.25f * q.w), pc);
+        split4<P>(up2_blend4(p, q), pc);
       } else {
         split4<P>(sv[i], pc);
       }
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(512) void wgrad_taps16_bf16s_kernel(const WgradTaps
       uint2 pc[P];
       if constexpr (UP) {
         const float4 p = sv[i], q = sv2[i];
-        split4<P>(make_float4(0.75f * p.x + 0.25f * q.x, 0.75f * p.y + 0.25f * q.y, 0.75f * p.z + 0.25f * q.z, 0.75f * p.w + 0.25f * q.w), pc);
+        split4<P>(up2_blend4(p, q), pc);
       } else {
         split4<P>(sv[i], pc);
       }

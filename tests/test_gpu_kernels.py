@@ -732,7 +732,8 @@ def test_conv_behind_upsample_fused(ops, geo, fcode, pieces, wcode):
     upo = torch.full_like(upd, float("nan"))
     yo = torch.full_like(yu, float("nan"))
     cvu.fwd(xd, wd, bd, yo, up_out=upo)
-    assert torch.equal(yo, yu) and torch.equal(upo, upd)
+    assert torch.equal(yo, yu)
+    assert torch.equal(upo, upd), (int(torch.isnan(upo).sum()), float((upo - upd).abs().nan_to_num(0.0).max()))
     with pytest.raises(RuntimeError):
         cvp.fwd(upd, wd, bd, yp, up_out=upo)
     tol = _SPLIT_TOL[pieces]
