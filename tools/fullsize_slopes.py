@@ -14,5 +14,9 @@ elif case == "config1":
 else:
     T._run(4096, True, prec, seed=51, expect=(), report=rep)
 rep.sort(key=lambda r: -r[2])
-for n, numel, e_hip, e_cpu in rep[:12]:
-    print(f"{n:48s} numel {numel:9d}  hip {e_hip:.2e}  fp32 oracle {e_cpu:.2e}")
+print("largest errors:")
+for n, numel, e_hip, e_cpu, gm, gmax in rep[:10]:
+    print(f"{n:48s} numel {numel:9d}  hip {e_hip:.2e}  fp32 oracle {e_cpu:.2e}  max|g| {gm:.3e}  (global {gmax:.3e})")
+print("single scalars (PReLU slopes):")
+for n, numel, e_hip, e_cpu, gm, gmax in sorted((r for r in rep if r[1] == 1), key=lambda r: r[0]):
+    print(f"{n:48s} g {gm:11.4e}  abs err hip {e_hip * (gm + 1e-3 * gmax):.2e}  oracle {e_cpu * (gm + 1e-3 * gmax):.2e}  rel hip {e_hip:.2e}  oracle {e_cpu:.2e}")
