@@ -485,6 +485,40 @@ def test_three_steps_and_grads_bf16x6(golden_dir, name, bf16x6_everywhere):
     test_three_steps_and_eval(golden_dir, name)
 
 
+@pytest.fixture(params=["f16x3b3", "bf16x6b3"])
+def fused_upsample_everywhere(request, monkeypatch):
+    """Every layer on the split kernels AND every decoder skip conv on the fused-upsample forward (halo kernels blending the
+    half-length input, the upsampled tensor left behind for the weight gradient), whatever the tile table says about the geometry."""
+    from scrubvae_amd import ops
+    from scrubvae_amd.model import residual
+    keep = (ops.PRECISION, ops.SPLIT_MIN_FLOPS)
+    ops.set_precision(request.param)
+    ops.SPLIT_MIN_FLOPS = 0.0
+    monkeypatch.setattr(residual, "FUSE_UPSAMPLE", "force")
+    yield
+    ops.set_precision(keep[0])
+    ops.SPLIT_MIN_FLOPS = keep[1]
+
+
+@pytest.mark.parametrize("name", ["vanilla_tiny", "full_tiny", "vanilla_default_j23_B4", "w256_6blocks_tiny"])
+def test_reference_fixtures_with_the_upsample_fused_into_the_skip_convs(golden_dir, name, fused_upsample_everywhere):
+    """Step 0 of the reference fixtures (outputs, every loss term, gradient norms: reference residual.py:153-170 and its autograd
+    through the fused forward + the by-product `up` tensor of the weight gradient), the gradients against the fp64 truth and three
+    optimizer steps, at the unfused path's tolerances."""
+    from scrubvae_amd.model import residual
+    test_step0_matches_reference_fixture(golden_dir, name)
+    if name in ("vanilla_tiny", "full_tiny"):
+        test_grads_vs_fp64_truth(golden_dir, name)
+        test_three_steps_and_eval(golden_dir, name)
+    # the fused path really ran: a model built now holds up2 convs for its decoder skip path
+    fx, cfg, loss_scale, opt, sd, data = load_fixture(golden_dir, name)
+    model, _ = build_model(cfg, sd)
+    model.train()
+    model(to_dev(data))
+    sk = [cv for key, cv in model._convs.items() if key[0].endswith(".sk")]
+    assert sk and all(cv.up2 for cv in sk if cv.kernel == 6), [(k, cv.up2) for k, cv in model._convs.items() if k[0].endswith(".sk")]
+
+
 # ------------------------------------------------------------------ full benchmark size: size-independent properties
 def _bench_size_model(precision, seed=0):
     from scrubvae_amd import ops
