@@ -10,6 +10,10 @@ LAYERS = [("enc3.c3", 4, 512, 1024, 5, 1, 2, False), ("dec0.t1", 4, 1024, 512, 5
 if os.environ.get("LAYERS") == "shallow":  # many rows, few channels: conv_in, the 64 / 128-channel blocks, the decoder's last skip conv
     LAYERS = [("conv_in", 64, 141, 64, 7, 1, 3, False), ("dec3.sk", 50, 128, 64, 6, 1, 2, False), ("dec2.sk", 26, 256, 128, 6, 1, 2, False),
               ("enc0.c3", 32, 64, 128, 5, 1, 2, False), ("dec3.t1", 25, 128, 64, 5, 1, 2, True), ("dec.out", 49, 64, 141, 22, 1, 3, True)]
+if os.environ.get("LAYERS") == "skinny":  # tiny outputs, 65 k - 200 k reduction rows: what the all-taps kernels serve at 20-30 % busy
+    LAYERS = [("enc0.c0", 64, 64, 64, 5, 2, 2, False), ("enc0.sk", 64, 64, 128, 5, 2, 2, False), ("enc0.c3", 32, 64, 128, 5, 1, 2, False),
+              ("enc1.c0", 32, 128, 128, 5, 2, 2, False), ("enc1.sk", 32, 128, 256, 5, 2, 2, False), ("dec2.t2", 13, 128, 128, 5, 2, 2, True),
+              ("dec3.t1", 25, 128, 64, 5, 1, 2, True), ("dec3.t2", 25, 64, 64, 5, 2, 2, True), ("dec3.sk", 50, 128, 64, 6, 1, 2, False)]
 if os.environ.get("LAYERS") == "conv_in":
     LAYERS = [("conv_in23", 64, 141, 64, 7, 1, 3, False), ("conv_in18", 64, 111, 64, 7, 1, 3, False)]
 codes = [int(c) for c in sys.argv[1:]] or [256256, 2256256]
