@@ -79,7 +79,7 @@ for key, cv in convs:
         if not base_p:
             continue
         d = cv.desc
-        tkey = f"{kind}@{base_p}:{d.batch}:{d.l_in}:{d.c_in}:{d.c_out}:{d.ld_in}:{d.ld_out}:{d.kernel}:{d.stride}:{d.padding}:{d.transposed}"
+        tkey = cv.tile_key(kind)
         cur_code, cur_p = int(cv.desc.tile[ops._KIND_ID[kind]]), cv._kind_pieces(kind)
         if not cur_p:  # this pass runs the fp32 kernel by the tuner's choice: leave it
             continue
