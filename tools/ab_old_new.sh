@@ -1,3 +1,8 @@
+#!/bin/bash
+# Same-box A/B of the working tree against an older revision at three batch sizes (configs[1] at B = 32 / 1024, configs[2] at 4096).
+# Prepare the old tree next to the new one before sending both to the GPU box (.ab_old/ is git-ignored, its .so travels with gpurun):
+#   rm -rf .ab_old && mkdir .ab_old && git archive <rev> | tar -x -C .ab_old && (cd .ab_old && python -c "from scrubvae_amd import build; build.build()")
+#   gpurun -- 'bash tools/ab_old_new.sh'
 set -o pipefail
 run() { # dir tag args...
   d=$1; tag=$2; shift 2
