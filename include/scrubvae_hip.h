@@ -104,7 +104,7 @@ int svae_conv_wgrad(const svae_conv_desc* d, const float* x, const float* dy, fl
  * svae_conv_split_weights from the fp32 master weights w[tap][c_in][c_out]; refresh it whenever
  * the weights change.  d->tile[0..1]: V*1000000 + BM*1000 + BN, V = kernel variant (waves per
  * workgroup / LDS buffering, see gemm_bf16s.hip; 16 / 17 / 18 (18: on the 16x16x32 MFMA): the 12-wave halo kernel with DMA-only loader waves, 256-row
- * tiles).  d->tile[2] for the split weight gradient: V*1000000 + BM*1000 + BN with V a bit set -- 1: single LDS buffer,
+ * tiles; 19 / 29: the 8-wave halo kernel on 256 x 160 / 256 x 256 tiles).  d->tile[2] for the split weight gradient: V*1000000 + BM*1000 + BN with V a bit set -- 1: single LDS buffer,
  * 2: XCD-aware workgroup order, 4: all taps of a tile in one workgroup (contiguous 5 / 6-tap geometries, 2 pieces;
  * SVAE_ERR_SHAPE otherwise), 8: that kernel on the 16x16x32 MFMA shape, 16: the taps folded into the dY columns (transposed
  * convs) or into the X channel rows (convs) of the tile -- one tile padding for all taps.  Results do not depend on the tile code beyond

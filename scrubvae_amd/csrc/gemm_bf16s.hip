@@ -690,6 +690,34 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
     // operand fragments of BOTH 16-deep k-steps are requested up front (one exposed LDS latency per stage, then 2 x
     // MT x NT x 6 MFMAs back to back); padding rows are zeroed with an AND mask (a select on the loaded value would be
     // turned into a divergent branch around the ds_read)
+    if constexpr (MT * NT >= 8) {
+      // 64 x 128 wave tiles (the 256 x 256 workgroup tile): 128 accumulator registers -- the fragments of ONE k-step at a time
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch = ks * 2 + h;
+        uint4 av[MT][P], bv[NT][P];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const unsigned mask = aval[mt] ? 0xffffffffu : 0u;
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            uint4 v = *reinterpret_cast<const uint4*>(smem + p * A_PIECE + arow[mt] * ROWB + ((ch ^ swz(arow[mt])) << 4));
+            v.x &= mask; v.y &= mask; v.z &= mask; v.w &= mask;
+            av[mt][p] = v;
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int p = 0; p < P; ++p)
+            bv[nt][p] = *reinterpret_cast<const uint4*>(bst + p * B_PIECE + b_addr[nt] + ((ch ^ b_sw[nt]) << 4));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_splitx<P, H>(av[mt], bv[nt], acc[mt][nt]);
+      }
+      return;
+    }
     uint4 av[2][MT][P], bv[2][NT][P];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -916,6 +944,17 @@ static int launch_halo256(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, 
   return SVAE_OK;
 }
 
+// V = 29: the halo kernel on 256 x 256 tiles, 4 x 2 waves of 64 x 128 (code 29128128; the fields of the code are placeholders): a
+// quarter fewer operand bytes per multiply through the CU's fetch path than 256 x 128.  Two pieces, images of <= 320 rows.
+static int launch_halo256x256(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
+  if (pieces != 2 && pieces != SVAE_PIECES_F16X2) { set_error("split gather: the 256 x 256 halo tile is built for 2 pieces"); return SVAE_ERR_SHAPE; }
+  // (a fused-upsample instance of this tile spills: 256 registers + 116 bytes of scratch, 516 us on dec0.sk against 476 + the 60 us upsample pass)
+  if (rows > 320 || sa.g.up) { set_error("split gather: 256 x 256 halo tile: image of %d rows does not fit / no fused upsample", rows); return SVAE_ERR_SHAPE; }
+  if (pieces == SVAE_PIECES_F16X2) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 256, 2, 4, 2, 320, true>), grid, dim3(512), 0, st, sa);
+  else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 256, 2, 4, 2, 320>), grid, dim3(512), 0, st, sa);
+  return SVAE_OK;
+}
+
 // V = 19: the halo kernel on 256 x 160 tiles, 8 x 1 waves of 32 x 160 (code 19128128; the fields of the code are placeholders).  For
 // the output conv (141 -> 144 channels): ONE column tile instead of three 64-wide ones -- 10 % instead of 25 % of the matrix work on
 // padding columns, and the activation image of a channel block staged once instead of three times.  Two pieces (bf16 or fp16).
@@ -945,10 +984,18 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
     set_error("split gather: the fused x2 upsample of the input exists in the halo kernels (tile codes 8 / 9), not in code %d", code);
     return SVAE_ERR_SHAPE;
   }
-  if (v >= 10 && v != 19) {
+  if (v >= 10 && v != 19 && v != 29) {
     bool handled = false;
     const int e = launch_split_halo_ws(sa, st, t, code, pieces, &handled);
     if (handled) return e;
+  }
+  if (v == 29) {  // 256 x 256 tiles
+    if (t.bm != 128 || t.bn != 128) { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_SHAPE; }
+    for (int p = 0; p < 2; ++p) g.blocks_m[p] = (int)((g.M[p] + 255) / 256);
+    const int nb = g.blocks_m[0] + g.blocks_m[1];
+    if (nb == 0) return SVAE_OK;
+    if (int e = launch_halo256x256(sa, dim3(nb, (g.N + 255) / 256), st, pieces, halo_rows(g, 256))) return e;
+    return check_launch("gather_halo_bf16s<256,256>");
   }
   if (v == 19) {  // 256 x 160 tiles
     if (t.bm != 128 || t.bn != 128) { set_error("split gather: tile code %d unsupported", code); return SVAE_ERR_SHAPE; }
@@ -1030,7 +1077,7 @@ extern "C" int svae_conv_fwd_stats_tiles(const svae_conv_desc* d) {
   build_plan(g, d, !d->transposed, d->l_out, d->l_in);
   Tile t;
   if (!decode_tile(d->tile[0], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; if (d->up2) { t.bm = 128; t.dma = 8; } }  // as launch_split_gather
-  const int bm = (t.dma == 9 || t.dma == 11 || t.dma >= 13) ? 256 : t.bm;
+  const int bm = (t.dma == 9 || t.dma == 11 || t.dma >= 13) ? 256 : t.bm;  // (13 .. 19 and 29: 256-row tiles)
   return (int)((g.M[0] + bm - 1) / bm + (g.M[1] + bm - 1) / bm);
 }
 
@@ -1081,7 +1128,7 @@ extern "C" int svae_conv_dgrad_stats_tiles(const svae_conv_desc* d, int* col_blo
   Tile t;
   if (!decode_tile(d->tile[1], t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; }
   const int bm = (t.dma == 9 || t.dma == 11 || t.dma >= 13) ? 256 : t.bm;
-  if (col_blocks) *col_blocks = t.dma == 19 ? (g.N + 159) / 160 : (g.N + t.bn - 1) / t.bn;
+  if (col_blocks) *col_blocks = t.dma == 19 ? (g.N + 159) / 160 : (t.dma == 29 ? (g.N + 255) / 256 : (g.N + t.bn - 1) / t.bn);
   return (int)((g.M[0] + bm - 1) / bm + (g.M[1] + bm - 1) / bm);
 }
 
@@ -1136,6 +1183,7 @@ extern "C" int svae_conv_split_tile(const svae_conv_desc* d, int kind, int* bm, 
   if (t.dma == 14 || t.dma == 15) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 264 ? 264 : 320; }
   if (t.dma >= 16 && t.dma <= 18) { const int r = halo_rows(g, 256); *bm = 256; *rmax = r <= 264 ? 264 : 320; }
   if (t.dma == 19) { const int r = halo_rows(g, 256); *bm = 256; *bn = 160; *rmax = r <= 320 ? 320 : 528; }
+  if (t.dma == 29) { *bm = 256; *bn = 256; *rmax = 320; }
   return SVAE_OK;
 }
 

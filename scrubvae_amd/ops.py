@@ -156,7 +156,7 @@ _SPLIT_GATHER_CODES = (_TILES + tuple(1000000 + c for c in _TILES) + (2128128, 2
                        + (10128128, 10128064, 11128128, 11128064)  # 10 / 11: wave-specialised halo kernel, 128- / 256-row tiles
                        + (12128128, 12128064, 13128128, 13128064)  # 12 / 13: the same with three weight-tile buffers
                        + (16128128, 16128064, 17128128, 17128064, 18128128, 18128064)
-                       + (19128128,))  # 19: halo kernel on 256 x 160 tiles, 8 x 1 waves (the fields of the code are placeholders): few-column outputs (conv_out: 144)  # 18: as 16 on the 16x16x32 MFMA; 16 / 17: 8 consumer + 4 DMA-only loader waves, 256-row tiles, consumers staggered / not
+                       + (19128128, 29128128))  # 19: halo kernel on 256 x 160 tiles, 8 x 1 waves (the fields of the code are placeholders): few-column outputs (conv_out: 144)  # 18: as 16 on the 16x16x32 MFMA; 16 / 17: 8 consumer + 4 DMA-only loader waves, 256-row tiles, consumers staggered / not
 # (codes 14128128 / 15128128 -- four consumer waves with 128 x 64 wave tiles, compiler-scheduled / pinned pipeline -- exist and are
 #  parity-tested but measured 0-15 % slower than 11 / 13 on every benchmark layer: not tuning candidates)
 _SPLIT_VARIANT = {0: "2, 2, 2, 1", 1: "2, 2, 1, 2", 2: "4, 2, 1, 2", 3: "4, 2, 2, 1"}
@@ -383,6 +383,8 @@ class Conv:
                     names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {320 if (up == 'true' and v == 9) else rm.value}, {H}, {up}>"
                 elif v == 19:
                     names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {P}, 8, 1, {rm.value}, {H}, false>"
+                elif v == 29:
+                    names[kind] = f"gather_halo_bf16s_kernel<256, 256, {P}, 4, 2, 320, {H}, false>"
                 elif v in (10, 11, 12, 13):
                     names[kind] = f"gather_halo_ws_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {rm.value}, 0, false, {3 if v >= 12 else 2}, {H}>"
                 elif v in (16, 17):
