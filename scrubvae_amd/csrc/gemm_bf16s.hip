@@ -499,7 +499,11 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
   constexpr int ROWB = SBK * 2;
   constexpr int A_PIECE = RMAX * ROWB, B_PIECE = BN * ROWB;
   constexpr int A_IMG = P * A_PIECE, B_STAGE = P * B_PIECE;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[A_IMG + 2 * B_STAGE];
+  // UP: the SOURCE rows of the image (flat rows (gbase >> 1) - 1 .. of the half-length tensor: RMAX / 2 + 3 of them at most) are what
+  // is fetched -- half as many requests as image rows -- and parked as raw fp32 rows in LDS; the image rows are blended from there
+  constexpr int SRC_ROWS = UP ? RMAX / 2 + 8 : 0, SPASS = UP ? (SRC_ROWS + RPP - 1) / RPP : 0, RAW_BYTES = SRC_ROWS * SBK * 4;
+  constexpr int RA_N = UP ? SPASS : APASS;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_IMG + 2 * B_STAGE + RAW_BYTES];
   __shared__ long long rowoff[BM];
 
   const int tid = threadIdx.x;
@@ -530,8 +534,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
 
   // ---- A image staging: 8 lanes per row, RPP rows per pass
   const int akq = tid & 7;
-  long long a_goff[APASS];
-  long long a_goff2[UP ? APASS : 1];
+  long long a_goff[RA_N];                      // UP: offsets of the SOURCE rows this thread fetches
+  bool s_ok[UP ? SPASS : 1];
+  int a_pq[UP ? APASS : 1];                    // UP: raw rows (p | q << 16) image row i blends: 0.75 raw[p] + 0.25 raw[q]
   bool a_row_ok[APASS];
   bool up_store[UP ? APASS : 1];
   long long own_end = 0;  // UP: this tile owns the upsampled rows [amin, own_end): up to the next tile's first anchor / the end of the tensor
@@ -547,13 +552,25 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
     a_row_ok[i] = r < R && grow >= 0 && grow < sa.rowsA;
     if constexpr (UP) {
       up_store[i] = sa.up_out != nullptr && blockIdx.y == 0 && a_row_ok[i] && grow >= amin && grow < own_end;
-      const long long gr = a_row_ok[i] ? grow : 0, b = gr / g.Lin;
-      const int ro = (int)(gr - b * g.Lin), L = g.Lin >> 1, ii = ro >> 1;
-      const int i2 = (ro & 1) ? (ii + 1 < L ? ii + 1 : L - 1) : (ii > 0 ? ii - 1 : 0);
-      a_goff[i] = (b * L + ii) * (long long)g.ldA;
-      a_goff2[i] = (b * L + i2) * (long long)g.ldA;
+      // image row (b, ro) = 0.75 x[b, ro / 2] + 0.25 x[b, ro / 2 -/+ 1] (clamped at the sample's ends); flat source row of the
+      // first term: grow >> 1 (samples are Lin = 2 L image rows and L source rows long)
+      const long long gr = a_row_ok[i] ? grow : gbase;
+      const int ro = (int)(gr % g.Lin);
+      const int pp = (int)((gr >> 1) - ((gbase >> 1) - 1));
+      const int qq = (gr & 1) ? (ro == g.Lin - 1 ? pp : pp + 1) : (ro == 0 ? pp : pp - 1);
+      a_pq[i] = a_row_ok[i] ? (pp | (qq << 16)) : 0;
     } else {
       a_goff[i] = (a_row_ok[i] ? grow : 0) * (long long)g.ldA;
+    }
+  }
+  if constexpr (UP) {
+    const long long s0 = (gbase >> 1) - 1, s_end = sa.rowsA >> 1;
+#pragma unroll
+    for (int i = 0; i < SPASS; ++i) {
+      const int j = (tid >> 3) + RPP * i;
+      const long long src = s0 + j;
+      s_ok[i] = j < SRC_ROWS && src >= 0 && src < s_end;
+      a_goff[i] = (s_ok[i] ? src : 0) * (long long)g.ldA;
     }
   }
   if (tid < BM) {
@@ -582,37 +599,52 @@ __global__ __launch_bounds__(64 * WR * WC) void gather_halo_bf16s_kernel(const S
   const long long tap_stride = kb_stride * sa.KB;
   const int ns = ntaps * sa.KB;
 
-  float4 ra[APASS];
-  float4 ra2[UP ? APASS : 1];
-  bool ra_ok[APASS];
+  float4 ra[RA_N];
+  bool ra_ok[RA_N];
   uint4 rb[BPASS];
-  int st_c = 0;  // UP: channel offset of the values load_a fetched last (store_a's by-product store)
+  int st_c = 0;        // UP: channel offset / validity of the values load_a fetched last (store_a's blend and by-product store)
+  bool st_kq = false;
   auto load_a = [&](int kb) {
     const int c0 = kb * SBK;
     const bool kq_ok = c0 + akq * 4 < g.Kc;
     const int cq = kq_ok ? c0 + akq * 4 : 0;
-    if constexpr (UP) st_c = cq;
+    if constexpr (UP) { st_c = cq; st_kq = kq_ok; }
 #pragma unroll
-    for (int i = 0; i < APASS; ++i) {
+    for (int i = 0; i < RA_N; ++i) {
       ra[i] = *reinterpret_cast<const float4*>(g.A + a_goff[i] + cq);
-      if constexpr (UP) ra2[i] = *reinterpret_cast<const float4*>(g.A + a_goff2[i] + cq);
-      ra_ok[i] = a_row_ok[i] && kq_ok;
+      if constexpr (UP) ra_ok[i] = s_ok[i] && kq_ok; else ra_ok[i] = a_row_ok[i] && kq_ok;
     }
   };
   auto store_a = [&]() {
+    [[maybe_unused]] unsigned char* const raw = smem + A_IMG + 2 * B_STAGE;
+    if constexpr (UP) {  // park the source rows, then blend the image rows from them
+#pragma unroll
+      for (int i = 0; i < SPASS; ++i) {
+        const int j = (tid >> 3) + RPP * i;
+        if ((i + 1) * RPP <= SRC_ROWS || j < SRC_ROWS)
+          *reinterpret_cast<float4*>(raw + j * (SBK * 4) + akq * 16) = ra_ok[i] ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const int r = (tid >> 3) + RPP * i;
       uint2 pc[P];
-      float4 v = ra[i];
+      float4 v;
+      bool v_ok;
       if constexpr (UP) {
-        const float4 q = ra2[i];
-        v = up2_blend4(v, q);
+        const float4 pv = *reinterpret_cast<const float4*>(raw + (a_pq[i] & 0xffff) * (SBK * 4) + akq * 16);
+        const float4 qv = *reinterpret_cast<const float4*>(raw + (a_pq[i] >> 16) * (SBK * 4) + akq * 16);
+        v = up2_blend4(pv, qv);
+        v_ok = a_row_ok[i] && st_kq;
         // by-product: the upsampled rows this tile OWNS (first row's anchor up to the next tile's) go to sa.up_out -- the operand of the
         // conv's weight gradient in the backward pass -- from the first column tile only; halo rows belong to the neighbours
-        if (up_store[i] && ra_ok[i]) *reinterpret_cast<float4*>(sa.up_out + (gbase + r) * (long long)g.ldA + st_c) = v;
+        if (up_store[i] && v_ok) *reinterpret_cast<float4*>(sa.up_out + (gbase + r) * (long long)g.ldA + st_c) = v;
+      } else {
+        v = ra[i];
+        v_ok = ra_ok[i];
       }
-      split4x<P, H>(ra_ok[i] ? v : make_float4(0.f, 0.f, 0.f, 0.f), pc);
+      split4x<P, H>(v_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f), pc);
       const int off = r * ROWB + (((akq >> 1) ^ swz(r)) << 4) + ((akq & 1) << 3);
       if ((i + 1) * RPP <= RMAX || r < RMAX) {
 #pragma unroll
@@ -948,8 +980,12 @@ static int launch_halo256(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, 
 // quarter fewer operand bytes per multiply through the CU's fetch path than 256 x 128.  Two pieces, images of <= 320 rows.
 static int launch_halo256x256(const SplitGatherArgs& sa, dim3 grid, hipStream_t st, int pieces, int rows) {
   if (pieces != 2 && pieces != SVAE_PIECES_F16X2) { set_error("split gather: the 256 x 256 halo tile is built for 2 pieces"); return SVAE_ERR_SHAPE; }
-  // (a fused-upsample instance of this tile spills: 256 registers + 116 bytes of scratch, 516 us on dec0.sk against 476 + the 60 us upsample pass)
-  if (rows > 320 || sa.g.up) { set_error("split gather: 256 x 256 halo tile: image of %d rows does not fit / no fused upsample", rows); return SVAE_ERR_SHAPE; }
+  if (rows > 320) { set_error("split gather: 256 x 256 halo tile: image of %d rows does not fit", rows); return SVAE_ERR_SHAPE; }
+  if (sa.g.up) {  // fused x2 upsample of the gathered operand
+    if (pieces == SVAE_PIECES_F16X2) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 256, 2, 4, 2, 320, true, true>), grid, dim3(512), 0, st, sa);
+    else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 256, 2, 4, 2, 320, false, true>), grid, dim3(512), 0, st, sa);
+    return SVAE_OK;
+  }
   if (pieces == SVAE_PIECES_F16X2) hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 256, 2, 4, 2, 320, true>), grid, dim3(512), 0, st, sa);
   else hipLaunchKernelGGL((gather_halo_bf16s_kernel<256, 256, 2, 4, 2, 320>), grid, dim3(512), 0, st, sa);
   return SVAE_OK;
@@ -980,8 +1016,8 @@ static int launch_split_gather(SplitGatherArgs& sa, hipStream_t st, int code, in
   Tile t;
   if (!decode_tile(code, t)) { t = pick_tile(g.M[0], g.M[1], g.N); t.dma = 1; if (g.up) { t.bm = 128; t.dma = 8; } }
   const int v = t.dma;
-  if (g.up && v != 8 && v != 9) {
-    set_error("split gather: the fused x2 upsample of the input exists in the halo kernels (tile codes 8 / 9), not in code %d", code);
+  if (g.up && v != 8 && v != 9 && v != 29) {
+    set_error("split gather: the fused x2 upsample of the input exists in the halo kernels (tile codes 8 / 9 / 29), not in code %d", code);
     return SVAE_ERR_SHAPE;
   }
   if (v >= 10 && v != 19 && v != 29) {

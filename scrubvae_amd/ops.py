@@ -384,7 +384,7 @@ class Conv:
                 elif v == 19:
                     names[kind] = f"gather_halo_bf16s_kernel<{bm.value}, {bn.value}, {P}, 8, 1, {rm.value}, {H}, false>"
                 elif v == 29:
-                    names[kind] = f"gather_halo_bf16s_kernel<256, 256, {P}, 4, 2, 320, {H}, false>"
+                    names[kind] = f"gather_halo_bf16s_kernel<256, 256, {P}, 4, 2, 320, {H}, {'true' if (self.up2 and kind == 'fwd') else 'false'}>"
                 elif v in (10, 11, 12, 13):
                     names[kind] = f"gather_halo_ws_bf16s_kernel<{bm.value}, {bn.value}, {P}, 4, 2, {rm.value}, 0, false, {3 if v >= 12 else 2}, {H}>"
                 elif v in (16, 17):

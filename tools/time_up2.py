@@ -14,7 +14,7 @@ COLD = os.environ.get("COLD", "1") != "0"
 FWD_PIECES = int(os.environ.get("FWD_PIECES", 22))
 LAYERS = [("dec0.sk", 4, 1024, 512), ("dec1.sk", 7, 512, 256), ("dec2.sk", 13, 256, 128), ("dec3.sk", 25, 128, 64)]
 FWD_PLAIN = [8128128, 9128128, 16128128, 17128128, 29128128]
-FWD_UP = [8128128, 8128064, 9128128, 9128064]
+FWD_UP = [8128128, 8128064, 9128128, 29128128]
 WG = [4064128, 6064128, 4128064, 6128064, 12064128, 14064128, 12128064, 14128064]
 _flush = None
 
